@@ -1,0 +1,271 @@
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container only (``/root/reference`` is mounted there, never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's importable, pure-torch files (model/*.py, loss/*.py; SURVEY.md
+section 8c), loads deterministic weights from ``bmhrl_amd.synthetic`` into them and stores
+inputs' seeds + expected outputs as small ``.npz`` files.  The fixtures are data only: no text
+of the reference is stored.  ``tests/test_oracle_golden.py`` pins ``oracle/bmhrl_oracle.py`` to
+them; the ``-m gpu`` tests pin the HIP path to the same files.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("BMHRL_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from bmhrl_amd import synthetic as syn  # noqa: E402
+
+quiet = contextlib.redirect_stdout(io.StringIO())
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def build_ref_agent(cfg, voc_size, seed):
+    from model.bm_hrl_agent import BMHrlAgent
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "critic.cp")
+        torch.save(syn.synthetic_critic_state(cfg.d_model_caps, seed=1), path)
+        cfg.rl_critic_path = path
+        ds = SimpleNamespace(trg_voc_size=voc_size, train_vocab=SimpleNamespace(vectors=None))
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            agent = BMHrlAgent(cfg, ds)
+    shapes = {k: tuple(v.shape) for k, v in agent.state_dict().items()}
+    sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=seed)
+    sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(cfg.d_model_caps, seed=1).items()})
+    agent.load_state_dict(sd)
+    agent.eval()
+    agent.set_inference_mode(True)
+    return agent, shapes
+
+
+def kat():
+    """Known-answer cases, re-derived from the reference here."""
+    from model.blocks import PositionalEncoder
+    from model.multihead_attention import attention
+    from model.bm_hrl_agent import Manager
+    from loss.label_smoothing import LabelSmoothing
+    from loss.biased_kl import BiasedKL, Reinforce
+    out = {}
+    out["pe8"] = PositionalEncoder(8, 0.0, seq_len=5).pos_enc_mat[0].numpy()
+    out["pe20"] = PositionalEncoder(20, 0.0, seq_len=40).pos_enc_mat[0].numpy()
+    Q = torch.ones(1, 1, 2, 4)
+    K = torch.arange(12.).reshape(1, 1, 3, 4) / 10
+    V = torch.arange(12.).reshape(1, 1, 3, 4)
+    out["att_allmasked"] = np_(attention(Q, K, V, torch.tensor([[[[False, False, False]]]])))
+    out["att_midmasked"] = np_(attention(Q, K, V, torch.tensor([[[[True, False, True]]]])))
+    mgr = Manager("cpu", 4, 1, 0.0)
+    B, L = 5, 6
+    g = (1 + torch.arange(B * L, dtype=torch.float32)).reshape(B, L, 1)
+    seg = torch.zeros(B, L, dtype=torch.int32)
+    for b, l in [(1, 1), (1, 3), (3, 5), (4, 2)]:
+        seg[b, l] = 1
+    out["expand_in"] = np_(g)
+    out["expand_seg"] = np_(seg)
+    out["expand_out"] = np_(mgr.expand_goals(g.clone(), seg))
+    B, S, V_ = 2, 3, 6
+    idx = torch.arange(B * S * V_, dtype=torch.float32).reshape(B, S, V_)
+    lp = torch.log_softmax((idx % 7) / 3, dim=-1)
+    out["a4_lp"] = np_(lp)
+    with contextlib.redirect_stderr(io.StringIO()):
+        out["a4_ls"] = np_(LabelSmoothing(0.7, 1)(lp, torch.tensor([[2, 4, 1], [5, 3, 2]])))
+        out["a4_ls_guard"] = np_(LabelSmoothing(0.7, 1)(lp, torch.tensor([[1, 4, 2], [5, 3, 2]])))
+        out["a4_bkl"] = np_(BiasedKL(0.7, 1)(lp, torch.tensor([[2, 4, 1], [5, 3, 2]]), torch.tensor([[2, 0, 3], [1, 3, 4]]),
+                                              torch.tensor([[.5, .25, 1.], [.8, 0., .1]])))
+        out["a4_reinforce"] = np_(Reinforce()(torch.exp(lp), torch.tensor([[2, 0, 3], [1, 3, 4]]),
+                                              torch.tensor([[.1, .2, .3], [.4, .5, .6]]), torch.tensor([[.3, .1, .0], [.2, .2, .9]])))
+    np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
+
+
+def losses_random():
+    from loss.label_smoothing import LabelSmoothing
+    from loss.biased_kl import BiasedKL, Reinforce
+    g = torch.Generator().manual_seed(11)
+    B, S, V = 3, 7, 37
+    logits = torch.randn(B, S, V, generator=g)
+    trg = torch.randint(2, V, (B, S), generator=g)
+    trg[0, 5:] = 1
+    trg[2, 3:] = 1
+    sampled = torch.randint(0, V, (B, S), generator=g)
+    score = torch.rand(B, S, generator=g)
+    baseline = torch.rand(B, S, generator=g) * 0.5
+    out = dict(logits=np_(logits), trg=np_(trg), sampled=np_(sampled), score=np_(score), baseline=np_(baseline))
+    with contextlib.redirect_stderr(io.StringIO()):
+        x = logits.clone().requires_grad_(True)
+        lp = torch.log_softmax(x, -1)
+        ls = LabelSmoothing(0.7, 1)(lp, trg)
+        n_tok = (trg != 1).sum()
+        (ls.sum() / n_tok).backward()
+        out["ls"] = np_(ls)
+        out["ls_grad_logits"] = np_(x.grad)
+        for stab in (False, True):
+            x = logits.clone().requires_grad_(True)
+            lp = torch.log_softmax(x, -1)
+            mask = trg != 1
+            p = torch.gather(torch.exp(lp), 2, sampled.unsqueeze(-1)).squeeze(-1)
+            sc = (score - baseline) * mask.float() if stab else score
+            amp = torch.clamp(sc * p * mask.sum(-1).reshape(-1, 1).float(), 0, 1)
+            div = BiasedKL(0.7, 1)(lp, trg, sampled, amp)
+            (div.sum() / (n_tok * 0.2)).backward()
+            tag = "stab" if stab else "raw"
+            out[f"bkl_{tag}"] = np_(div)
+            out[f"bkl_{tag}_amp"] = np_(amp)
+            out[f"bkl_{tag}_grad_logits"] = np_(x.grad)
+        x = logits.clone().requires_grad_(True)
+        probs = torch.softmax(x, -1)
+        r = Reinforce()(probs, sampled, score, baseline)
+        r.backward()
+        out["reinforce"] = np_(r)
+        out["reinforce_grad_logits"] = np_(x.grad)
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+
+
+def mha_cases():
+    from model.multihead_attention import MultiheadedAttention
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    # (dQ, dK, H, d_model, Sq, Sk, tag)
+    for dq, dk, H, D, Sq, Sk, tag in [(48, 48, 4, 64, 7, 7, "self"), (48, 24, 4, 64, 7, 9, "cross"), (8, 20, 2, 64, 6, 6, "goal")]:
+        with quiet:
+            m = MultiheadedAttention(dq, dk, dk, H, 0.0, D)
+        sd = syn.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=3)
+        m.load_state_dict(sd)
+        B = 3
+        q = torch.randn(B, Sq, dq, generator=g)
+        kv = q if tag == "self" else torch.randn(B, Sk, dk, generator=g)
+        if tag == "goal":
+            mask = torch.tril(torch.ones(B, Sq, Sk, dtype=torch.bool))
+            mask[1, :, 4:] = False
+        else:
+            mask = torch.ones(B, 1, Sk, dtype=torch.bool)
+            mask[0, 0, Sk - 2:] = False
+            mask[2, 0, :] = False  # a fully masked sample -> uniform attention
+        y = m(q, kv, kv, mask)
+        out[f"{tag}_q"], out[f"{tag}_kv"], out[f"{tag}_mask"], out[f"{tag}_out"] = np_(q), np_(kv), np_(mask), np_(y)
+    np.savez_compressed(os.path.join(HERE, "mha.npz"), **out)
+
+
+def agent_tiny():
+    cfg = syn.tiny_cfg()
+    Vsz = 50
+    agent, shapes = build_ref_agent(cfg, Vsz, seed=0)
+    from model.masking import make_masks
+    from loss.label_smoothing import LabelSmoothing
+    from loss.biased_kl import BiasedKL
+    B, Tv, Ta, L = 4, 7, 9, 6
+    batch = syn.synthetic_batch(B, Tv, Ta, L, Vsz, seed=7, d_vid=cfg.d_vid, d_aud=cfg.d_aud, min_len=3)
+    cap = batch["captions"]
+    trg_in, trg_y = cap[:, :-1], cap[:, 1:]
+    fs = {"rgb": batch["rgb"], "flow": batch["flow"], "audio": batch["audio"]}
+    masks = make_masks(fs, trg_in, "audio_video", 1)
+    x = (fs["rgb"] + fs["flow"], fs["audio"])
+    out = {"state_keys": np.array(sorted(shapes)), "state_shapes": np.array([str(shapes[k]) for k in sorted(shapes)])}
+    with quiet, contextlib.redirect_stderr(io.StringIO()):
+        pred, wf, mf, goals, seg = agent(x, trg_in, masks)
+        out.update(pred=np_(pred), worker_feat=np_(wf), manager_feat=np_(mf), goals=np_(goals), seg=np_(seg))
+        # encoder outputs, for layer-level checks
+        V = agent.pos_enc_V(x[0]); A = agent.pos_enc_A(x[1])
+        Va, Av = agent.bm_enc((V, A), masks)
+        out.update(enc_v=np_(Va), enc_a=np_(Av))
+        # warmstart step loss + all grads
+        agent.zero_grad()
+        n_tok = (trg_y != 1).sum()
+        loss = LabelSmoothing(0.7, 1)(pred, trg_y).sum() / n_tok
+        loss.backward()
+        out["ws_loss"] = np_(loss)
+        for k, p in agent.named_parameters():
+            if p.grad is not None:
+                out["ws_grad/" + k] = np_(p.grad)
+        # mixed prediction (trg tuple + factor)
+        yhat = torch.roll(trg_in, 1, dims=0)
+        pm = agent(x, (trg_in, yhat), masks, 0.25)[0]
+        out["yhat"] = np_(yhat)
+        out["pred_mixed"] = np_(pm)
+        # worker RL step with given sample / reward / baseline (worker phase: teach_worker)
+        agent.teach_worker()
+        agent.zero_grad()
+        pred, wf, mf, goals, seg = agent(x, trg_in, masks)
+        g = torch.Generator().manual_seed(3)
+        sampled = torch.distributions.Categorical(torch.exp(pred)).sample() if False else torch.multinomial(
+            torch.exp(pred).reshape(-1, Vsz), 1, generator=g).reshape(B, L)
+        score = syn.synthetic_rewards(B, L, seed=2)
+        mask = trg_y != 1
+        p = torch.gather(torch.exp(pred), 2, sampled.unsqueeze(-1)).squeeze(-1)
+        amp = torch.clamp(score * p * mask.sum(-1).reshape(-1, 1).float(), 0, 1)
+        div = BiasedKL(0.7, 1)(pred, trg_y, sampled, amp)
+        rl = div.sum() / (n_tok * 0.2)
+        rl.backward()
+        out.update(rl_sampled=np_(sampled), rl_score=np_(score), rl_loss=np_(rl))
+        for k, p_ in agent.named_parameters():
+            if p_.grad is not None:
+                out["rl_grad/" + k] = np_(p_.grad)
+    np.savez_compressed(os.path.join(HERE, "agent_tiny.npz"), **out)
+
+
+def critic_case():
+    from model.bm_hrl_agent import SegmentCritic
+    cfg = syn.tiny_cfg()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "critic.cp")
+        torch.save(syn.synthetic_critic_state(cfg.d_model_caps, seed=1), path)
+        cfg.rl_critic_path = path
+        with quiet:
+            c = SegmentCritic(cfg)
+    g = torch.Generator().manual_seed(9)
+    emb = torch.randn(3, 6, cfg.d_model_caps, generator=g) * 2
+    np.savez_compressed(os.path.join(HERE, "critic.npz"), emb=np_(emb), out=np_(c(emb)))
+
+
+def sample_clip_decode():
+    """BASELINE config 1: the reference's sample clip, greedy decode on the CPU reference path."""
+    from captioning_datasets.load_features import crop_a_segment
+    from model.masking import make_masks
+    cfg = syn.default_cfg(dout_p=0.0, rl_critic_score_threshhold=1.0)
+    Vsz = 2000  # the real vocabulary needs torchtext/spaCy (absent); V is a parameter
+    agent, _ = build_ref_agent(cfg, Vsz, seed=0)
+    feats = {}
+    for k, f in (("rgb", "rgb"), ("flow", "flow"), ("audio", "vggish")):
+        a = torch.from_numpy(np.load(os.path.join(REF, "sample", f"women_long_jump_{f}.npy"))).float()
+        feats[k] = crop_a_segment(a, 0, 15, 16).unsqueeze(0)
+    trg = torch.full((1, 1), 2, dtype=torch.long)
+    first = None
+    with torch.no_grad(), quiet:
+        while trg.shape[-1] <= 12:
+            masks = make_masks(feats, trg, "audio_video", 1)
+            pred = agent.inference((feats["rgb"] + feats["flow"], feats["audio"]), trg, masks)
+            if first is None:
+                first = pred[0, -1].clone()
+            nxt = pred[:, -1].argmax(-1, keepdim=True)
+            trg = torch.cat([trg, nxt], -1)
+    top2 = torch.topk(first, 2).values
+    np.savez_compressed(os.path.join(HERE, "sample_clip.npz"), rgb=np_(feats["rgb"]),
+                        flow=np_(feats["flow"]), audio=np_(feats["audio"]),
+                        tokens=np_(trg), first_logp=np_(first), first_margin=np_(top2[0] - top2[1]), voc=np.array(Vsz))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    kat()
+    losses_random()
+    mha_cases()
+    critic_case()
+    agent_tiny()
+    sample_clip_decode()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,187 @@
+"""Pins oracle/bmhrl_oracle.py to the fixtures the reference itself produced (tests/golden/make_golden.py)
+and to the hand-typed known answers of SURVEY.md Appendix A.  CPU only."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from bmhrl_amd import synthetic as syn
+from oracle import bmhrl_oracle as O
+
+T = torch.from_numpy
+
+
+def close(a, b, tol=1e-5, floor=1e-6):
+    """max|a-b| <= tol * max(max|b|, floor).  Gradients that are analytically zero (key biases under
+    softmax shift invariance) are fp32 noise of ~1e-9 in the reference; ``floor`` keeps them out."""
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), floor)
+    assert err <= tol, err
+
+
+def agent_sd(g):
+    shapes = {k: eval(s) for k, s in zip(g["state_keys"].tolist(), g["state_shapes"].tolist())}
+    sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=0)
+    cfg = syn.tiny_cfg()
+    sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(cfg.d_model_caps, seed=1).items()})
+    return cfg, sd
+
+
+def test_posenc_known_answers(golden):
+    g = golden("kat")
+    close(O.posenc_table(5, 8), g["pe8"], 1e-12)
+    close(O.posenc_table(40, 20), g["pe20"], 1e-12)
+    # SURVEY.md Appendix A1, typed by hand
+    pe1 = [0.8414709848, 0.9504152803, 0.0998334166, 0.9995000417, 0.0099998333, 0.9999950000, 0.0009999998, 0.9999999500]
+    close(O.posenc_table(3, 8)[1], np.array(pe1), 1e-9)
+
+
+def test_attention_masking_known_answers(golden):
+    g = golden("kat")
+    Q = torch.ones(1, 1, 2, 4)
+    K = torch.arange(12.).reshape(1, 1, 3, 4) / 10
+    V = torch.arange(12.).reshape(1, 1, 3, 4)
+    a = O.sdp_attention(Q, K, V, torch.tensor([[[[False, False, False]]]]))
+    close(a, g["att_allmasked"])
+    close(a[0, 0, 0], np.array([4., 5., 6., 7.]))  # A2: fully masked row -> uniform mean of V
+    close(O.sdp_attention(Q, K, V, torch.tensor([[[[True, False, True]]]])), g["att_midmasked"])
+
+
+def test_expand_goals_known_answer(golden):
+    g = golden("kat")
+    out = O.expand_goals(T(g["expand_in"]), T(g["expand_seg"]))
+    close(out, g["expand_out"], 0)
+    a3 = [[0, 0, 0, 0, 0, 0], [8, 8, 10, 10, 0, 0], [13, 14, 15, 16, 17, 18], [24] * 6, [27, 27, 27, 28, 29, 30]]
+    close(out[:, :, 0], np.array(a3, dtype=np.float32), 0)
+
+
+def test_losses_known_answers(golden):
+    g = golden("kat")
+    lp = T(g["a4_lp"])
+    ls = O.label_smoothing(lp, torch.tensor([[2, 4, 1], [5, 3, 2]]), 0.7, 1)
+    close(ls, g["a4_ls"])
+    close(ls.sum(1), np.array([0.3006364, 0.2642519, 0.0, 0.6130040, 0.3660113, 0.3579281], dtype=np.float32), 2e-6)
+    # the idx.sum()>0 guard: only padded flat index is 0 -> row NOT zeroed
+    close(O.label_smoothing(lp, torch.tensor([[1, 4, 2], [5, 3, 2]]), 0.7, 1), g["a4_ls_guard"])
+    bk = O.biased_kl_loss(lp, torch.tensor([[2, 4, 1], [5, 3, 2]]), torch.tensor([[2, 0, 3], [1, 3, 4]]),
+                          torch.tensor([[.5, .25, 1.], [.8, 0., .1]]), 0.7, 1)
+    close(bk, g["a4_bkl"])
+    assert abs(float(bk.sum()) - 1.3885437) < 1e-5
+    r = O.reinforce_loss(torch.exp(lp), torch.tensor([[2, 0, 3], [1, 3, 4]]), torch.tensor([[.1, .2, .3], [.4, .5, .6]]),
+                         torch.tensor([[.3, .1, .0], [.2, .2, .9]]))
+    close(r, g["a4_reinforce"])
+    assert abs(float(r) - 0.1814150) < 1e-6
+
+
+def test_losses_random_with_grads(golden):
+    g = golden("losses")
+    logits, trg, sampled = T(g["logits"]), T(g["trg"]), T(g["sampled"])
+    score, baseline = T(g["score"]), T(g["baseline"])
+    x = logits.clone().requires_grad_(True)
+    lp = torch.log_softmax(x, -1)
+    close(O.label_smoothing(lp, trg, 0.7, 1), g["ls"])
+    O.warmstart_loss(lp, trg, 0.7, 1).backward()
+    close(x.grad, g["ls_grad_logits"])
+    for stab, tag in ((False, "raw"), (True, "stab")):
+        x = logits.clone().requires_grad_(True)
+        lp = torch.log_softmax(x, -1)
+        div, _ = O.worker_biased_kl(lp, trg, sampled, score, baseline, trg != 1, 0.7, 1, stab)
+        close(div, g[f"bkl_{tag}"])
+        O.worker_rl_loss(lp, trg, sampled, score, baseline, 0.7, 1, stab).backward()
+        close(x.grad, g[f"bkl_{tag}_grad_logits"])  # includes the path through the amplitude (A5)
+    x = logits.clone().requires_grad_(True)
+    r = O.reinforce_loss(torch.softmax(x, -1), sampled, score, baseline)
+    r.backward()
+    close(r, g["reinforce"])
+    close(x.grad, g["reinforce_grad_logits"])
+
+
+@pytest.mark.parametrize("tag,dq,dk,H", [("self", 48, 48, 4), ("cross", 48, 24, 4), ("goal", 8, 20, 2)])
+def test_mha(golden, tag, dq, dk, H):
+    g = golden("mha")
+    D = 64
+    shapes = {}
+    for n, (o, i) in {"linear_Q2d": (D, dq), "linear_K2d": (D, dk), "linear_V2d": (D, dk), "linear_d2Q": (dq, D)}.items():
+        shapes[f"{n}.weight"] = (o, i)
+        shapes[f"{n}.bias"] = (o,)
+    sd = {"m." + k: v for k, v in syn.fill_state_dict(shapes, seed=3).items()}
+    q, kv, mask = T(g[f"{tag}_q"]), T(g[f"{tag}_kv"]), T(g[f"{tag}_mask"])
+    close(O.mha(sd, "m", q, kv, kv, mask, H), g[f"{tag}_out"])
+
+
+def test_critic(golden):
+    g = golden("critic")
+    cfg = syn.tiny_cfg()
+    sd = {"critic." + k: v for k, v in syn.synthetic_critic_state(cfg.d_model_caps, seed=1).items()}
+    close(O.segment_critic(sd, "critic", T(g["emb"])), g["out"])
+
+
+def _tiny_inputs(cfg):
+    B, Tv, Ta, L, V = 4, 7, 9, 6, 50
+    b = syn.synthetic_batch(B, Tv, Ta, L, V, seed=7, d_vid=cfg.d_vid, d_aud=cfg.d_aud, min_len=3)
+    cap = b["captions"]
+    trg_in, trg_y = cap[:, :-1], cap[:, 1:]
+    masks = O.make_masks(b["rgb"], b["audio"], trg_in, 1)
+    return b, trg_in, trg_y, masks
+
+
+def test_agent_forward_and_warmstart_grads(golden):
+    g = golden("agent_tiny")
+    cfg, sd = agent_sd(g)
+    for k in sd:
+        if not k.startswith("critic."):
+            sd[k] = sd[k].clone().requires_grad_(True)
+    b, trg_in, trg_y, masks = _tiny_inputs(cfg)
+    x = (b["rgb"] + b["flow"], b["audio"])
+    pred, wf, mf, goals, seg = O.agent_forward(sd, cfg, x, trg_in, masks)
+    close(pred, g["pred"]); close(wf, g["worker_feat"]); close(mf, g["manager_feat"]); close(goals, g["goals"])
+    assert np.array_equal(seg.numpy(), g["seg"])
+    assert seg.sum() > 0, "fixture must exercise expand_goals"
+    loss = O.warmstart_loss(pred, trg_y, 0.7, 1)
+    close(loss, g["ws_loss"])
+    loss.backward()
+    n = 0
+    for k in g:
+        if k.startswith("ws_grad/"):
+            name = k[len("ws_grad/"):]
+            close(sd[name].grad, g[k], 1e-4, 1e-4)
+            n += 1
+    assert n > 100
+    # parameters the reference never reaches get no gradient (hard parts)
+    assert sd["bm_worker_fus.decoder.layers.0.feed_forward.fc1.weight"].grad is None
+    assert "ws_grad/bm_worker_fus.decoder.layers.0.feed_forward.fc1.weight" not in g
+
+
+def test_agent_mixed_and_rl_step(golden):
+    g = golden("agent_tiny")
+    cfg, sd = agent_sd(g)
+    b, trg_in, trg_y, masks = _tiny_inputs(cfg)
+    x = (b["rgb"] + b["flow"], b["audio"])
+    close(O.agent_forward(sd, cfg, x, (trg_in, T(g["yhat"])), masks, 0.25)[0], g["pred_mixed"])
+    for k in sd:
+        if not k.startswith("critic."):
+            sd[k] = sd[k].clone().requires_grad_(True)
+    pred = O.agent_forward(sd, cfg, x, trg_in, masks)[0]
+    loss = O.worker_rl_loss(pred, trg_y, T(g["rl_sampled"]), T(g["rl_score"]), None, 0.7, 1, False)
+    close(loss, g["rl_loss"])
+    loss.backward()
+    for k in g:
+        if k.startswith("rl_grad/"):
+            close(sd[k[len("rl_grad/"):]].grad, g[k], 1e-4, 1e-4)
+
+
+def test_sample_clip_greedy_decode(golden):
+    """BASELINE config 1: reference sample clip, greedy decode (tokens produced by the reference)."""
+    g = golden("sample_clip")
+    cfg = syn.default_cfg(dout_p=0.0, rl_critic_score_threshhold=1.0)
+    from bmhrl_amd.model.bm_hrl_agent import agent_state_shapes
+    V = int(g["voc"])
+    sd = syn.fill_state_dict(agent_state_shapes(cfg, V, with_critic=False), seed=0)
+    sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(cfg.d_model_caps, seed=1).items()})
+    rgb, flow, audio = T(g["rgb"]), T(g["flow"]), T(g["audio"])
+    toks = O.greedy_decode(sd, cfg, rgb, flow, audio, 12, 2, 3, 1)
+    assert np.array_equal(toks.numpy(), g["tokens"])
