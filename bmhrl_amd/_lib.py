@@ -1,0 +1,91 @@
+"""ctypes binding of bmhrl_amd/csrc/libbmhrl_hip.so (C ABI: include/bmhrl_hip.h).
+
+The library is required: loading raises if it is missing (no CPU or eager fallback exists).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbmhrl_hip.so")
+
+i32, i64, u64, f32 = C.c_int32, C.c_int64, C.c_uint64, C.c_float
+ptr = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K", i32), ("batch1", i32), ("batch2", i32),
+        ("A", ptr), ("lda", i64), ("a_sb1", i64), ("a_sb2", i64), ("a_trans", i32),
+        ("B", ptr), ("ldb", i64), ("b_sb1", i64), ("b_sb2", i64), ("b_trans", i32),
+        ("C", ptr), ("ldc", i64), ("c_sb1", i64), ("c_sb2", i64),
+        ("Cb", ptr), ("ldcb", i64), ("cb_sb1", i64), ("cb_sb2", i64),
+        ("epilogue", i32), ("alpha", f32), ("relu", i32), ("accumulate", i32),
+        ("bias", ptr),
+        ("residual", ptr), ("ldr", i64), ("r_sb1", i64), ("r_sb2", i64),
+        ("mask", ptr), ("mask_sb1", i64), ("mask_sm", i64),
+        ("rowvec", ptr), ("rowvec2", ptr), ("rv_sb1", i64), ("rv_sb2", i64),
+        ("aux", ptr), ("ldaux", i64), ("aux_sb1", i64), ("aux_sb2", i64),
+        ("dropout_p", f32), ("seed", u64),
+    ]
+
+
+# name -> argtypes (every entry point of include/bmhrl_hip.h; tests check the .so exports all of them)
+PROTOTYPES = {
+    "bmhrl_gemm": [C.POINTER(GemmDesc), ptr],
+    "bmhrl_attention_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, f32,
+                            f32, u64, ptr],
+    "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, ptr],
+    "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, i32, i32, i32, i32, ptr],
+    "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, i64, i32, ptr],
+    "bmhrl_add_posenc": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, f32, u64, ptr],
+    "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr],
+    "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
+    "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr],
+    "bmhrl_colsum_bf16": [ptr, i64, ptr, i32, i64, i32, ptr],
+    "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "bmhrl_gate_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_expand_goals_index": [ptr, ptr, i32, i32, ptr],
+    "bmhrl_gather_rows": [ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
+    "bmhrl_scatter_add_rows": [ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_log_softmax": [ptr, i64, i64, i32, ptr],
+    "bmhrl_smooth_kl_fwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, i32, ptr],
+    "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, ptr, i64, i32, ptr],
+    "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr],
+    "bmhrl_reinforce_fwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, f32, ptr],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m bmhrl_amd.build` (hipcc --offload-arch=gfx950). "
+            "bmhrl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.bmhrl_hip_arch.restype = C.c_char_p
+    lib.bmhrl_hip_abi_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = "invalid argument" if rc < 0 else "hipError_t"
+        raise HipError(f"{what} failed: {kind} {rc}")

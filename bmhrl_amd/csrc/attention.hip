@@ -1,0 +1,327 @@
+// Fused scaled-dot-product attention forward for gfx950 (flash style, d_k = 256, bf16 MFMA, fp32 softmax).
+//
+// Replaces attention() + head split/merge of the reference (model/multihead_attention.py:7-31,75-86) for the
+// self- and cross-modal attentions of BMEncoderLayer and the caption->memory attentions of BMFusionLayer.
+//
+// Formulation (everything transposed so that a query row lives on ONE lane):
+//   S^T (keys x q)  = K_tile . Q^T          A = K rows from LDS (ds_read_b128), B = Q^T fragments held in registers
+//   softmax over keys = over the 16 accumulator registers of a lane + one lane^32 exchange (no LDS, no permute)
+//   O^T (d x q)    += V^T . P^T             A = V^T read from the row-major V tile by ds_read_b64_tr_b16,
+//                                           B = the S^T accumulator converted to bf16 in place (k order of the
+//                                           accumulator: key = 16s + 8(j>>2) + 4h + (j&3))
+// so the running max / sum / rescale factors are per-lane scalars and O^T rescaling needs no cross-lane traffic.
+//
+// Work split: block = QW x KW waves.  Wave (qi, ki) owns 32 query rows and the keys [32 ki, 32 ki + 32) of every
+// (32 KW)-key tile; waves with the same qi keep private online-softmax state and are merged once at the end through
+// LDS.  QW=2,KW=2 gives 64-row blocks (B*H*Sq/64 >= 256 blocks at the reference shapes) with 4 MFMA-busy SIMDs per
+// CU; K/V tiles are staged global -> registers -> LDS one tile ahead (two LDS buffers, one barrier per tile).
+#include "common.h"
+#include "../../include/bmhrl_hip.h"
+
+namespace {
+
+constexpr int DK = 256;
+constexpr int SKS = DK + 8;   // K tile row stride (elements): +16 B -> conflict-free ds_read_b128 across 16 rows
+constexpr int SVS = DK + 32;  // V tile row stride: +64 B -> the 4 rows of a tr-read block hit disjoint bank quarters
+
+struct AttnArgs {
+  const bf16_t* Q; long ldq;
+  const bf16_t* K; long ldk;
+  const bf16_t* V; long ldv;
+  bf16_t* O; long ldo;
+  float* row_max; float* row_sum;
+  const uint8_t* mask; long mask_sb, mask_sq;
+  int B, H, Sq, Sk;
+  float scale, dropout_p; uint64_t seed;
+  int q_tiles;
+};
+
+template <int QW, int KW>
+__global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int NT = 64 * QW * KW;
+  constexpr int BN = 32 * KW;                       // keys per tile
+  constexpr int K_ELEMS = BN * SKS, V_ELEMS = BN * SVS;
+  constexpr int STAGE = K_ELEMS + V_ELEMS;
+  constexpr int CH = BN * (DK / 8) / NT;            // 16-byte chunks per thread per operand per tile
+  static_assert(BN * (DK / 8) % NT == 0, "tile must divide evenly");
+  constexpr int MERGE_FLOATS = (KW > 1) ? (KW - 1) * QW * 130 * 64 : 0;
+  constexpr int LDS_BYTES = (2 * STAGE * 2 > MERGE_FLOATS * 4) ? 2 * STAGE * 2 : MERGE_FLOATS * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = wave / KW, ki = wave % KW;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+
+  // blockIdx.x = bh * q_tiles + q_tile : all q-tiles of one (b, head) are adjacent so they share K/V in L2.
+  const int bh = blockIdx.x / p.q_tiles, qt = blockIdx.x % p.q_tiles;
+  const int b = bh / p.H, hd = bh % p.H;
+  const int q_row = qt * (32 * QW) + qi * 32 + r32;       // this lane's query row
+  const bool q_ok = q_row < p.Sq;
+
+  const bf16_t* __restrict__ Kg = p.K + (long)b * p.Sk * p.ldk + hd * DK;
+  const bf16_t* __restrict__ Vg = p.V + (long)b * p.Sk * p.ldv + hd * DK;
+
+  // Q^T fragments: lane (q = r32, h) holds Q[q][16*step + 8h .. +8)
+  bf16x8 qf[DK / 16];
+  {
+    const bf16_t* qp = p.Q + ((long)b * p.Sq + (q_ok ? q_row : 0)) * p.ldq + hd * DK + 8 * h;
+#pragma unroll
+    for (int s = 0; s < DK / 16; ++s) qf[s] = q_ok ? *reinterpret_cast<const bf16x8*>(qp + 16 * s) : zero_bf16x8();
+  }
+
+  bf16x8 rk[CH], rv[CH];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + i * NT;
+      const int row = c / (DK / 8), col = c % (DK / 8);
+      const bool ok = (k0 + row) < p.Sk;
+      rk[i] = ok ? *reinterpret_cast<const bf16x8*>(Kg + (long)(k0 + row) * p.ldk + col * 8) : zero_bf16x8();
+      rv[i] = ok ? *reinterpret_cast<const bf16x8*>(Vg + (long)(k0 + row) * p.ldv + col * 8) : zero_bf16x8();
+    }
+  };
+  auto store_tile = [&](int buf) {
+    bf16_t* sK = smem + buf * STAGE;
+    bf16_t* sV = sK + K_ELEMS;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + i * NT;
+      const int row = c / (DK / 8), col = c % (DK / 8);
+      *reinterpret_cast<bf16x8*>(sK + row * SKS + col * 8) = rk[i];
+      *reinterpret_cast<bf16x8*>(sV + row * SVS + col * 8) = rv[i];
+    }
+  };
+
+  f32x16 o[DK / 32];
+#pragma unroll
+  for (int d = 0; d < DK / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const uint8_t* __restrict__ mrow = p.mask ? p.mask + (long)b * p.mask_sb + (long)(q_ok ? q_row : 0) * p.mask_sq : nullptr;
+
+  const int nt = (p.Sk + BN - 1) / BN;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const int k0 = t * BN;
+    if (t + 1 < nt) load_tile(k0 + BN);
+    const bf16_t* sK = smem + cur * STAGE;
+    const bf16_t* sV = sK + K_ELEMS;
+
+    // ---- S^T = K . Q^T for this wave's 32 keys
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const bf16_t* kbase = sK + (32 * ki + r32) * SKS + 8 * h;
+#pragma unroll
+    for (int st = 0; st < DK / 16; ++st) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + 16 * st);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+    }
+
+    // ---- masked, scaled scores; online softmax (per-lane state: this lane's query row)
+    const int key0 = k0 + 32 * ki + 4 * h;
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2);
+      float v = s[r] * p.scale;
+      if (mrow && key < p.Sk && !mrow[key]) v = NEG_MASK;
+      if (key >= p.Sk) v = -INFINITY;
+      s[r] = v;
+      m_tile = fmaxf(m_tile, v);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(s[r] - m_safe);
+      s[r] = e;
+      psum += e;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int d = 0; d < DK / 32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    bf16x8 pf[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pf[0][j] = (bf16_t)s[j];
+      pf[1][j] = (bf16_t)s[8 + j];
+    }
+
+    // ---- O^T += V^T . P^T ; V^T fragments come transposed out of the row-major V tile
+    const bf16_t* vbase = sV + (32 * ki + 4 * h + q4) * SVS + 16 * g1 + 4 * p4;
+#pragma unroll
+    for (int d = 0; d < DK / 32; ++d) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16_t* vp = vbase + (16 * ks) * SVS + 32 * d;
+        const bf16x8 vf = join8(lds_read_tr4(vp), lds_read_tr4(vp + 8 * SVS));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
+      }
+    }
+
+    if (t + 1 < nt) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- merge the KW partial states of each query block (ki > 0 publish through LDS, ki == 0 combines)
+  if (KW > 1) {
+    float* mg = reinterpret_cast<float*>(smem_raw);
+    // layout: [(ki-1)*QW + qi][130 rows][64 lanes] ; rows 0..127 = o regs, 128 = m, 129 = l
+    if (ki > 0) {
+      float* dst = mg + ((ki - 1) * QW + qi) * 130 * 64 + lane;
+#pragma unroll
+      for (int d = 0; d < DK / 32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = o[d][r];
+      dst[128 * 64] = m_run;
+      dst[129 * 64] = l_run;
+    }
+    __syncthreads();
+    if (ki == 0) {
+#pragma unroll
+      for (int k2 = 1; k2 < KW; ++k2) {
+        const float* src = mg + ((k2 - 1) * QW + qi) * 130 * 64 + lane;
+        const float m2 = src[128 * 64], l2 = src[129 * 64];
+        const float m = fmaxf(m_run, m2);
+        const float ms = (m == -INFINITY) ? 0.f : m;
+        const float a1 = __expf(m_run - ms), a2 = __expf(m2 - ms);
+#pragma unroll
+        for (int d = 0; d < DK / 32; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a1 + src[(d * 16 + r) * 64] * a2;
+        l_run = l_run * a1 + l2 * a2;
+        m_run = m;
+      }
+    }
+  }
+
+  if (ki == 0 && q_ok) {
+    const float inv = 1.0f / l_run;
+    if (h == 0) {
+      const long si = ((long)b * p.H + hd) * p.Sq + q_row;
+      p.row_max[si] = m_run;
+      p.row_sum[si] = l_run;
+    }
+    bf16_t* op = p.O + ((long)b * p.Sq + q_row) * p.ldo + hd * DK + 4 * h;
+    const uint64_t ebase = ((uint64_t)b * p.Sq + q_row) * (uint64_t)(p.H * DK) + hd * DK + 4 * h;
+#pragma unroll
+    for (int d = 0; d < DK / 32; ++d) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = o[d][4 * g + j] * inv;
+          if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, p.seed, ebase + 32 * d + 8 * g + j);
+          w[j] = (bf16_t)v;
+        }
+        *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * g) = w;
+      }
+    }
+  }
+}
+
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, long lddo, const bf16_t* __restrict__ O, long ldo,
+                                  float* __restrict__ delta, int B, int H, int Sq, int dk) {
+  // one wave per (b, q, h)
+  const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long total = (long)B * Sq * H;
+  if (wid >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int hd = wid % H;
+  const long bq = wid / H;
+  const bf16_t* a = dO + bq * lddo + (long)hd * dk;
+  const bf16_t* c = O + bq * ldo + (long)hd * dk;
+  float acc = 0.f;
+  for (int d = lane * 8; d < dk; d += 64 * 8) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + d);
+    const bf16x8 y = *reinterpret_cast<const bf16x8*>(c + d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const long b = bq / Sq, q = bq % Sq;
+    delta[(b * H + hd) * Sq + q] = acc;
+  }
+}
+
+// Row softmax for the materialised small-Sq path: one wave per row, fp32 in, bf16 out.
+__global__ void softmax_rows_kernel(const float* __restrict__ S, long lds, bf16_t* __restrict__ P, long ldp, long rows,
+                                    int cols) {
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* s = S + row * lds;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, s[c]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int c = lane; c < cols; c += 64) l += __expf(s[c] - m);
+  l = wave_sum(l);
+  const float inv = 1.f / l;
+  bf16_t* pr = P + row * ldp;
+  for (int c = lane; c < cols; c += 64) pr[c] = (bf16_t)(__expf(s[c] - m) * inv);
+}
+
+}  // namespace
+
+extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                                   void* O, int64_t ldo, float* row_max, float* row_sum, const uint8_t* mask,
+                                   int64_t mask_sb, int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk,
+                                   int32_t dk, float scale, float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(Q && K && V && O && row_max && row_sum);
+  BMHRL_CHECK_ARG(dk == DK);  // d_model 1024 / H 4 of the reference; other head sizes use the materialised path
+  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
+  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
+  BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldk >= (int64_t)H * DK && ldv >= (int64_t)H * DK && ldo >= (int64_t)H * DK);
+  BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && ((uintptr_t)O & 7) == 0);
+  BMHRL_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
+  AttnArgs a;
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+  a.O = (bf16_t*)O; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
+  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed;
+  constexpr int QW = 2, KW = 2;
+  a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
+  dim3 grid((unsigned)(B * H * a.q_tiles)), block(64 * QW * KW);
+  hipLaunchKernelGGL((attn_fwd_kernel<QW, KW>), grid, block, 0, (hipStream_t)stream, a);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, int32_t B,
+                                int32_t H, int32_t Sq, int32_t dk, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dO && O && delta && dk % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0);
+  const long total = (long)B * Sq * H;
+  dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  hipLaunchKernelGGL(attn_delta_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dO, (long)lddo,
+                     (const bf16_t*)O, (long)ldo, delta, B, H, Sq, dk);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
+                                  bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(S && P && rows > 0 && cols > 0);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, (hipStream_t)stream, S, (long)lds, (bf16_t*)P, (long)ldp,
+                     (long)rows, cols);
+  return hip_status(hipGetLastError());
+}

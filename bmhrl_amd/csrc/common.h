@@ -1,0 +1,92 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16 bf16, LDS transposed reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define WAVE 64
+#define NEG_MASK (-1e9f)  // reference: masked_fill(mask == False, -1e9), model/multihead_attention.py:22
+
+#define BMHRL_CHECK_ARG(cond) \
+  do {                        \
+    if (!(cond)) return -22;  \
+  } while (0)
+
+static inline int hip_status(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blocks of up to 1024 threads; `red` is a 16-float LDS scratch.  All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// Counter-based RNG: one 32-bit hash per (seed, element id).  Forward and backward regenerate the same
+// dropout mask from the element id, so no mask tensor is stored.
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  return (hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+}
+// keep-scale of inverted dropout: 0 if dropped, 1/(1-p) if kept
+__device__ __forceinline__ float dropout_scale(float p, uint64_t seed, uint64_t idx) {
+  return uniform01(seed, idx) < p ? 0.f : 1.0f / (1.0f - p);
+}
+
+__device__ __forceinline__ bf16x8 zero_bf16x8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.f;
+  return z;
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, reads a 4-row x 16-column block of 16-bit elements; lane 4q+p of the
+// group passes the address of row q, columns 4p..4p+3; lane i receives column i, row q in element q.
+__device__ __forceinline__ bf16x4 lds_read_tr4(const bf16_t* p) {
+  short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ bf16x8 join8(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}

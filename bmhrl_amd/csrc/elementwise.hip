@@ -1,0 +1,393 @@
+// HBM-bound kernels of the hot path for gfx950: LayerNorm fwd/bwd, feature add + positional encoding, embedding,
+// casts with dropout, bias-gradient column sums, fusion gate, expand_goals, fused Adam.
+// One wave (64 lanes) owns one row wherever a row reduction is needed; reductions are wavefront shuffles.
+#include "common.h"
+#include "../../include/bmhrl_hip.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 256 threads = 4 waves = 4 rows in flight per block
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              bf16_t* __restrict__ yb, long ldy, float* __restrict__ yf, float* __restrict__ mean,
+                              float* __restrict__ rstd, long rows, int D) {
+  const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += xr[c];
+  const float mu = wave_sum(s) / D;
+  float v = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float d = xr[c] - mu;
+    v += d * d;
+  }
+  const float rs = rsqrtf(wave_sum(v) / D + 1e-5f);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  for (int c = lane; c < D; c += 64) {
+    const float y = (xr[c] - mu) * rs * gamma[c] + beta[c];
+    if (yb) yb[row * ldy + c] = (bf16_t)y;
+    if (yf) yf[row * D + c] = y;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.  Each wave walks `rows_per_wave` rows and keeps
+// its lanes' dgamma/dbeta partial sums in registers (<= 16 columns per lane, D <= 1024), then one atomic per column.
+constexpr int LN_MAXC = 16;
+__global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                              int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D,
+                              int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const long r0 = wave_id * rows_per_wave;
+  float dg[LN_MAXC], db[LN_MAXC];
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) dg[i] = db[i] = 0.f;
+  for (long row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + row * D;
+    const float* dyr = dy + row * D;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) {
+        const float xh = (xr[c] - mu) * rs, g = dyr[c] * gamma[c];
+        s1 += g;
+        s2 += g * xh;
+        dg[i] += dyr[c] * xh;
+        db[i] += dyr[c];
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) {
+        const float xh = (xr[c] - mu) * rs, g = dyr[c] * gamma[c];
+        const float v = rs * (g - s1 - xh * s2);
+        float* d = dx + row * D + c;
+        *d = accumulate_dx ? (*d + v) : v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      if (dgamma) atomicAdd(dgamma + c, dg[i]);
+      if (dbeta) atomicAdd(dbeta + c, db[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K1: add + posenc
+__global__ void add_posenc_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ pe,
+                                  float* __restrict__ out, bf16_t* __restrict__ ob, long ldob, int S, int D, long total,
+                                  float p, uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % D;
+    const long row = i / D;
+    const int s = row % S;
+    float v = a[i] + (b ? b[i] : 0.f) + pe[(long)s * D + c];
+    if (p > 0.f) v *= dropout_scale(p, seed, i);
+    out[i] = v;
+    if (ob) ob[row * ldob + c] = (bf16_t)v;
+  }
+}
+
+__global__ void embed_posenc_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ tok2, float mix,
+                                    const float* __restrict__ table, const float* __restrict__ pe, float* __restrict__ emb,
+                                    float* __restrict__ out, int L, int D, long total, float scale, float p, uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % D;
+    const long row = i / D;
+    const int l = row % L;
+    float e = table[tok[row] * D + c] * scale;
+    if (tok2) e = e * (1.f - mix) + table[tok2[row] * D + c] * scale * mix;
+    if (emb) emb[i] = e;
+    float v = e + pe[(long)l * D + c];
+    if (p > 0.f) v *= dropout_scale(p, seed, i);
+    out[i] = v;
+  }
+}
+
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ tok2, float mix,
+                                 const float* __restrict__ dC, float* __restrict__ dtable, int D, long total, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % D;
+    const long row = i / D;
+    const float g = dC[i] * scale;
+    if (tok2) {
+      atomicAdd(dtable + tok[row] * D + c, g * (1.f - mix));
+      atomicAdd(dtable + tok2[row] * D + c, g * mix);
+    } else {
+      atomicAdd(dtable + tok[row] * D + c, g);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ casts / sums
+__global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows,
+                                 int cols, float scale, float p, uint64_t seed) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % cols;
+    const long r = i / cols;
+    float v = x[r * ldx + c] * scale;
+    if (p > 0.f) v *= dropout_scale(p, seed, i);
+    y[r * ldy + c] = (bf16_t)v;
+  }
+}
+
+// db[n] (+)= sum_m dY[m][n]: block = 256 threads = 64 columns x 4 row groups, grid.y splits the rows.
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ld, float* __restrict__ db, long rows, int cols,
+                                   int rows_per_block) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  float acc = 0.f;
+  if (col < cols)
+    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += 4) acc += (float)dY[r * ld + col];
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < cols) atomicAdd(db + col, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+// ------------------------------------------------------------------------------------------------ fusion gate
+__device__ __forceinline__ float gate_of(const float* a_v) {
+  const float a = fminf(fmaxf(a_v[0], -2.f), 2.f);
+  return 1.f / (1.f + __expf(-a));
+}
+__global__ void gate_fwd_kernel(const float* __restrict__ cv, const float* __restrict__ ca, const float* __restrict__ a_v,
+                                float* __restrict__ out, bf16_t* __restrict__ ob, long ldob, int D, long total) {
+  const float g = gate_of(a_v);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float v = g * cv[i] + (1.f - g) * ca[i];
+    out[i] = v;
+    if (ob) ob[(i / D) * ldob + (i % D)] = (bf16_t)v;
+  }
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ cv, const float* __restrict__ ca,
+                                const float* __restrict__ a_v, float* __restrict__ dcv, float* __restrict__ dca,
+                                float* __restrict__ da_v, long total) {
+  __shared__ float red[16];
+  const float a = a_v[0];
+  const float g = gate_of(a_v);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float d = dout[i];
+    dcv[i] = g * d;
+    dca[i] = (1.f - g) * d;
+    acc += d * (cv[i] - ca[i]);
+  }
+  acc = block_sum(acc, red);
+  // d sigmoid(clamp(a)) / da = g(1-g) inside [-2, 2], 0 outside (torch.clamp passes gradient on the closed interval)
+  if (threadIdx.x == 0 && da_v) atomicAdd(da_v, (a >= -2.f && a <= 2.f) ? acc * g * (1.f - g) : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ expand_goals
+// One thread per batch row reproduces the reference's sequential visit order (model/bm_hrl_agent.py:415-429):
+//  rows with labels: each segment [prev_end+1 .. end] reads the goal at `end`; the tail after the last label is
+//  zeroed iff a LATER row has a label; rows without labels are untouched, except row 0, which is zeroed when any
+//  later row has a label (old_b starts at 0).
+__global__ void expand_goals_index_kernel(const int32_t* __restrict__ seg, int32_t* __restrict__ src, int B, int L) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  bool later = false;
+  for (int bb = b + 1; bb < B && !later; ++bb)
+    for (int l = 0; l < L; ++l)
+      if (seg[bb * L + l] != 0) { later = true; break; }
+  int prev = 0;
+  bool any = false;
+  for (int l = 0; l < L; ++l) {
+    if (seg[b * L + l] != 0) {
+      for (int j = prev; j <= l; ++j) src[b * L + j] = b * L + l;
+      prev = l + 1;
+      any = true;
+    }
+  }
+  const bool zero_tail = later && (any || b == 0);
+  for (int j = prev; j < L; ++j) src[b * L + j] = zero_tail ? -1 : b * L + j;
+}
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ src, float* __restrict__ out,
+                                   bf16_t* __restrict__ ob, long ldob, int D, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = i % D;
+    const int s = src[r];
+    const float v = s >= 0 ? x[(long)s * D + c] : 0.f;
+    out[i] = v;
+    if (ob) ob[r * ldob + c] = (bf16_t)v;
+  }
+}
+__global__ void scatter_add_rows_kernel(const float* __restrict__ dout, const int32_t* __restrict__ src,
+                                        float* __restrict__ dx, int D, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int s = src[r];
+    if (s >= 0) atomicAdd(dx + (long)s * D + (i % D), dout[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                            float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    // torch.optim.Adam: denom = sqrt(v)/sqrt(bias_correction2) + eps ; p -= lr/bias_correction1 * m/denom
+    p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+inline unsigned grid_for(long total, int block = 256, int cap = 2048) {
+  long g = (total + block - 1) / block;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int bmhrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, int64_t ldy,
+                                   float* y_f32, float* mean, float* rstd, int64_t rows, int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32) && rows > 0 && D > 0);
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+  hipLaunchKernelGGL(ln_fwd_kernel, grid, block, 0, S_(stream), x, gamma, beta, (bf16_t*)y_bf16, (long)ldy, y_f32, mean,
+                     rstd, (long)rows, D);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, float* dx, int32_t accumulate_dx, float* dgamma, float* dbeta,
+                                   int64_t rows, int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 64 * LN_MAXC);
+  // enough waves to fill the chip (2048+), at most 32 rows per wave so the atomics stay ~rows/32 per column
+  int rpw = (int)((rows + 4095) / 4096);
+  if (rpw < 1) rpw = 1;
+  if (rpw > 32) rpw = 32;
+  const long waves = (rows + rpw - 1) / rpw;
+  dim3 grid((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+  hipLaunchKernelGGL(ln_bwd_kernel, grid, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, accumulate_dx, dgamma, dbeta,
+                     (long)rows, D, rpw);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_add_posenc(const float* a, const float* b, const float* pe, float* out, void* out_bf16, int64_t ldob,
+                                int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(a && pe && out && B > 0 && S > 0 && D > 0);
+  const long total = (long)B * S * D;
+  hipLaunchKernelGGL(add_posenc_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), a, b, pe, out, (bf16_t*)out_bf16,
+                     (long)ldob, S, D, total, dropout_p, seed);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_embed_posenc(const int64_t* tok, const int64_t* tok2, float mix, const float* table, const float* pe,
+                                  float* emb_out, float* out, int32_t B, int32_t L, int32_t D, float scale,
+                                  float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(tok && table && pe && out && B > 0 && L > 0 && D > 0);
+  const long total = (long)B * L * D;
+  hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), tok, tok2, mix, table, pe,
+                     emb_out, out, L, D, total, scale, dropout_p, seed);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const float* dC, float* dtable,
+                               int32_t B, int32_t L, int32_t D, float scale, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(tok && dC && dtable && B > 0 && L > 0 && D > 0);
+  const long total = (long)B * L * D;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), tok, tok2, mix, dC, dtable, D,
+                     total, scale);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
+                               float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y,
+                     (long)ldy, (long)rows, cols, scale, dropout_p, seed);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t accumulate, int64_t rows, int32_t cols,
+                                 bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dY && db && rows > 0 && cols > 0);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * cols, S_(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  const int rpb = 128;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows, cols, rpb);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_gate_fwd(const float* cv, const float* ca, const float* a_v, float* out, void* out_bf16, int64_t ldob,
+                              int64_t rows, int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(cv && ca && a_v && out && rows > 0 && D > 0);
+  const long total = rows * D;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), cv, ca, a_v, out, (bf16_t*)out_bf16,
+                     (long)ldob, D, total);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_gate_bwd(const float* dout, const float* cv, const float* ca, const float* a_v, float* dcv, float* dca,
+                              float* da_v, int64_t rows, int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dout && cv && ca && a_v && dcv && dca && rows > 0 && D > 0);
+  const long total = rows * D;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(total, 256, 256)), dim3(256), 0, S_(stream), dout, cv, ca, a_v, dcv, dca,
+                     da_v, total);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_expand_goals_index(const int32_t* seg, int32_t* src, int32_t B, int32_t L, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(seg && src && B > 0 && L > 0);
+  hipLaunchKernelGGL(expand_goals_index_kernel, dim3((B + 63) / 64), dim3(64), 0, S_(stream), seg, src, B, L);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_gather_rows(const float* x, const int32_t* src, float* out, void* out_bf16, int64_t ldob, int64_t rows,
+                                 int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && src && out && rows > 0 && D > 0);
+  const long total = rows * D;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), x, src, out, (bf16_t*)out_bf16,
+                     (long)ldob, D, total);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, float* dx, int64_t rows, int32_t D,
+                                      bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dout && src && dx && rows > 0 && D > 0);
+  const long total = rows * D;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), dout, src, dx, D, total);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                               bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, S_(stream), param, grad, exp_avg, exp_avg_sq,
+                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
+extern "C" int bmhrl_hip_abi_version(void) { return 1; }

@@ -1,0 +1,248 @@
+// Per-token loss step for gfx950: log-softmax over the vocabulary, label-smoothing KL / biased KL (forward row
+// sums and the gradient w.r.t. the logits, including the path through the reward amplitude), categorical sampling
+// and the REINFORCE-with-baseline terms.  All HBM-bound: one 256-thread block per (b, l) row of V log-probs; the
+// smoothed target distribution is never materialised (closed form over the <= 3 special columns of a row).
+//
+// Reference: model/bm_hrl_agent.py:463-466 (log-softmax), loss/label_smoothing.py:12-32, loss/biased_kl.py:22-53,69-81,
+// epoch_loops/captioning_bmrl_loops.py:271-334,409-416.
+#include "common.h"
+#include "../../include/bmhrl_hip.h"
+
+namespace {
+
+__global__ void log_softmax_kernel(float* __restrict__ x, long ld, int V) {
+  __shared__ float red[16];
+  float* r = x + (long)blockIdx.x * ld;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) m = fmaxf(m, r[c]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) s += __expf(r[c] - m);
+  s = block_sum(s, red);
+  const float lse = m + __logf(s);
+  for (int c = threadIdx.x; c < V; c += blockDim.x) r[c] -= lse;
+}
+
+// The target distribution of one row, as the reference builds it:
+//   dist[v] = u ; dist[t] = keep*(1-amp) ; dist[pad] = 0 ; dist[a] += keep*amp ; (pad row -> 0) ; (+1e-8 if biased)
+struct RowTarget {
+  int t, a;          // target token, sampled token (-1 = plain label smoothing)
+  bool zero_row;     // pad row that the reference zeroes
+  float u, keep, amp, eps;
+  int pad;
+  __device__ float at(int c) const {  // dist (+eps) at column c
+    if (zero_row) return eps;
+    float v = (c == pad) ? 0.f : (c == t ? keep * (1.f - amp) : u);
+    if (c == a) v += keep * amp;
+    return v + eps;
+  }
+};
+
+__device__ __forceinline__ float xlogx(float d) { return d > 0.f ? d * __logf(d) : 0.f; }
+
+// pad rows are zeroed only if the SUM of padded flat indices is positive: row r > 0 always qualifies itself; row 0
+// qualifies only if some other row is padded too.
+__device__ bool pad_row_zeroed(const int64_t* trg, long row, long rows, int pad, int zero_pad_rows) {
+  if (trg[row] != pad) return false;
+  if (zero_pad_rows >= 0) return zero_pad_rows != 0;
+  if (row > 0) return true;
+  for (long r = 1; r < rows; ++r)
+    if (trg[r] == pad) return true;
+  return false;
+}
+
+__device__ RowTarget make_target(const float* lp, const int64_t* trg, const int64_t* btrg, const float* score,
+                                 const float* n_row, float smoothing, int pad, int zero_pad_rows, long row, long rows,
+                                 int V, float* raw_amp) {
+  RowTarget T;
+  T.t = (int)trg[row];
+  T.a = btrg ? (int)btrg[row] : -1;
+  T.u = smoothing / (V - 2);
+  T.keep = 1.f - smoothing;
+  T.pad = pad;
+  T.eps = btrg ? 1e-8f : 0.f;
+  T.zero_row = pad_row_zeroed(trg, row, rows, pad, zero_pad_rows);
+  T.amp = 0.f;
+  if (btrg) {
+    const float raw = score[row] * __expf(lp[T.a]) * n_row[row];
+    if (raw_amp) *raw_amp = raw;
+    T.amp = fminf(fmaxf(raw, 0.f), 1.f);
+  }
+  return T;
+}
+
+__global__ void smooth_kl_fwd_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
+                                     const int64_t* __restrict__ btrg, const float* __restrict__ score,
+                                     const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
+                                     float* __restrict__ row_loss, float* __restrict__ amp_out, long rows, int V) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* lp = logp + row * ld;
+  float s1 = 0.f;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) s1 += lp[c];
+  s1 = block_sum(s1, red);
+  if (threadIdx.x != 0) return;
+  const RowTarget T = make_target(lp, trg, btrg, score, n_row, smoothing, pad, zero_pad_rows, row, rows, V, nullptr);
+  if (amp_out) amp_out[row] = T.amp;
+  // special columns: unique({t, pad, a}); every other column holds d0
+  int sp[3], ns = 0;
+  sp[ns++] = T.t;
+  if (T.pad != T.t) sp[ns++] = T.pad;
+  if (T.a >= 0 && T.a != T.t && T.a != T.pad) sp[ns++] = T.a;
+  const float d0 = T.zero_row ? T.eps : T.u + T.eps;
+  float loss = 0.f, lp_special = 0.f;
+  for (int i = 0; i < ns; ++i) {
+    const float d = T.at(sp[i]);
+    loss += xlogx(d) - d * lp[sp[i]];
+    lp_special += lp[sp[i]];
+  }
+  loss += (float)(V - ns) * xlogx(d0) - d0 * (s1 - lp_special);
+  row_loss[row] = loss;
+}
+
+__global__ void smooth_kl_bwd_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
+                                     const int64_t* __restrict__ btrg, const float* __restrict__ score,
+                                     const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
+                                     const float* __restrict__ loss_scale, bf16_t* __restrict__ gb, long ldg,
+                                     float* __restrict__ gf, long rows, int V) {
+  const long row = blockIdx.x;
+  const float* lp = logp + row * ld;
+  float raw = 0.f;
+  const RowTarget T = make_target(lp, trg, btrg, score, n_row, smoothing, pad, zero_pad_rows, row, rows, V, &raw);
+  const float scale = loss_scale[0];
+  // d rowloss / d logp_v = -dist'_v, plus the amplitude path on column a:
+  //   d rowloss/d amp = keep * [ (log d'_a + 1 - logp_a) - (t != pad) * (log d'_t + 1 - logp_t) ],  d amp/d logp_a = raw
+  float extra_a = 0.f;
+  if (T.a >= 0 && !T.zero_row && raw >= 0.f && raw <= 1.f) {
+    const float da = T.at(T.a);
+    float g = __logf(da) + 1.f - lp[T.a];
+    if (T.t != T.pad) {
+      const float dt = T.at(T.t);
+      g -= __logf(dt) + 1.f - lp[T.t];
+    }
+    extra_a = T.keep * g * raw;
+  }
+  int ns = 1 + (T.pad != T.t) + (T.a >= 0 && T.a != T.t && T.a != T.pad);
+  const float d0 = T.zero_row ? T.eps : T.u + T.eps;
+  float dsum = (float)(V - ns) * d0 + T.at(T.t);
+  if (T.pad != T.t) dsum += T.at(T.pad);
+  if (T.a >= 0 && T.a != T.t && T.a != T.pad) dsum += T.at(T.a);
+  const float G = -dsum + extra_a;  // sum_v d rowloss / d logp_v
+  for (int c = threadIdx.x; c < V; c += blockDim.x) {
+    float g = -T.at(c) - __expf(lp[c]) * G;
+    if (c == T.a) g += extra_a;
+    g *= scale;
+    if (gb) gb[row * ldg + c] = (bf16_t)g;
+    if (gf) gf[row * (long)V + c] = g;
+  }
+}
+
+// Inverse-CDF categorical sample with one uniform per row (or arg-max), block per row.
+__global__ void sample_kernel(const float* __restrict__ logp, long ld, int64_t* __restrict__ out, float* __restrict__ p_out,
+                              int V, int greedy, uint64_t seed) {
+  __shared__ float part[256];
+  __shared__ int best_i[256];
+  const long row = blockIdx.x;
+  const float* lp = logp + row * ld;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int chunk = (V + nt - 1) / nt;
+  const int c0 = tid * chunk, c1 = min(V, c0 + chunk);
+  if (greedy) {
+    float bv = -INFINITY;
+    int bi = V;
+    for (int c = c0; c < c1; ++c)
+      if (lp[c] > bv) { bv = lp[c]; bi = c; }
+    part[tid] = bv;
+    best_i[tid] = bi;
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < nt; ++i)
+        if (part[i] > bv) { bv = part[i]; bi = best_i[i]; }  // first maximum wins, like torch.argmax
+      out[row] = bi;
+      if (p_out) p_out[row] = __expf(lp[bi]);
+    }
+    return;
+  }
+  float s = 0.f;
+  for (int c = c0; c < c1; ++c) s += __expf(lp[c]);
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.f;
+    for (int i = 0; i < nt; ++i) total += part[i];
+    const float u = uniform01(seed, (uint64_t)row) * total;
+    float acc = 0.f;
+    int t = 0;
+    while (t < nt - 1 && acc + part[t] <= u) acc += part[t++];
+    int c = t * chunk;
+    const int ce = min(V, c + chunk);
+    int pick = ce - 1;
+    for (; c < ce; ++c) {
+      acc += __expf(lp[c]);
+      if (acc > u) { pick = c; break; }
+    }
+    if (pick < 0) pick = 0;
+    out[row] = pick;
+    if (p_out) p_out[row] = __expf(lp[pick]);
+  }
+}
+
+__global__ void reinforce_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ action,
+                                 const float* __restrict__ value, const float* __restrict__ critic_value,
+                                 float* __restrict__ row_policy, float* __restrict__ row_value, long rows) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float pa = fminf(fmaxf(__expf(logp[row * ld + action[row]]), 1e-5f), 1.f - 1e-5f);
+  const float adv = value[row] - critic_value[row];
+  row_policy[row] = -adv * __logf(pa);
+  row_value[row] = adv * adv;
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int bmhrl_log_softmax(float* logits, int64_t ld, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logits && rows > 0 && V > 0 && ld >= V);
+  hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logits, (long)ld, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
+                                   const float* score, const float* n_row, float smoothing, int32_t pad_idx,
+                                   int32_t zero_pad_rows, float* row_loss, float* amp_out, int64_t rows, int32_t V,
+                                   bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && trg && row_loss && rows > 0 && V > 2);
+  BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
+  hipLaunchKernelGGL(smooth_kl_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
+                     score, n_row, smoothing, pad_idx, zero_pad_rows, row_loss, amp_out, (long)rows, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
+                                   const float* score, const float* n_row, float smoothing, int32_t pad_idx,
+                                   int32_t zero_pad_rows, const float* loss_scale, void* dlogits_bf16, int64_t ldg,
+                                   float* dlogits_f32, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && trg && loss_scale && (dlogits_bf16 || dlogits_f32) && rows > 0 && V > 2);
+  BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
+  hipLaunchKernelGGL(smooth_kl_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
+                     score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, (bf16_t*)dlogits_bf16, (long)ldg,
+                     dlogits_f32, (long)rows, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
+                                   int32_t greedy, uint64_t seed, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && out && rows > 0 && V > 0);
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, out, p_out, V, greedy, seed);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_reinforce_fwd(const float* logp, int64_t ld, const int64_t* action, const float* value,
+                                   const float* critic_value, float* row_policy, float* row_value, int64_t rows, int32_t V,
+                                   bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && action && value && critic_value && row_policy && row_value && rows > 0 && V > 0);
+  hipLaunchKernelGGL(reinforce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S_(stream), logp, (long)ld, action,
+                     value, critic_value, row_policy, row_value, (long)rows);
+  return hip_status(hipGetLastError());
+}

@@ -1,0 +1,176 @@
+"""Thin torch-tensor wrappers over the C ABI (include/bmhrl_hip.h).  Tensors only lend their device pointers;
+every call is enqueued on torch's current HIP stream.  No wrapper has a CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+EPI_LINEAR, EPI_PROB, EPI_DSCORE = 0, 1, 2
+
+
+def pad8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("bmhrl_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def bf16_zeros(rows: int, cols: int, device) -> torch.Tensor:
+    """bf16 (rows, pad8(cols)) buffer with zeroed padding columns."""
+    return torch.zeros(rows, pad8(cols), dtype=torch.bfloat16, device=device)
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, a_trans=False, b_trans=False,
+         batch: Tuple[int, int] = (1, 1), a_strides=(0, 0), b_strides=(0, 0), a_off=0, b_off=0,
+         C_f32: Optional[torch.Tensor] = None, ldc=0, c_strides=(0, 0), c_off=0,
+         C_bf16: Optional[torch.Tensor] = None, ldcb=0, cb_strides=(0, 0), cb_off=0,
+         epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
+         r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
+         aux=None, ldaux=0, aux_strides=(0, 0), dropout_p=0.0, seed=0) -> None:
+    """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
+    _need_cuda(A, B, C_f32, C_bf16)
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.batch1, d.batch2 = batch
+    d.A = A.data_ptr() + 2 * a_off; d.lda = lda; d.a_sb1, d.a_sb2 = a_strides; d.a_trans = int(a_trans)
+    d.B = B.data_ptr() + 2 * b_off; d.ldb = ldb; d.b_sb1, d.b_sb2 = b_strides; d.b_trans = int(b_trans)
+    d.C = None if C_f32 is None else C_f32.data_ptr() + 4 * c_off; d.ldc = ldc; d.c_sb1, d.c_sb2 = c_strides
+    d.Cb = None if C_bf16 is None else C_bf16.data_ptr() + 2 * cb_off; d.ldcb = ldcb; d.cb_sb1, d.cb_sb2 = cb_strides
+    d.epilogue = epilogue; d.alpha = alpha; d.relu = int(relu); d.accumulate = int(accumulate)
+    d.bias = _p(bias)
+    d.residual = _p(residual); d.ldr = ldr; d.r_sb1, d.r_sb2 = r_strides
+    d.mask = _p(mask); d.mask_sb1 = mask_sb1; d.mask_sm = mask_sm
+    d.rowvec = _p(rowvec); d.rowvec2 = _p(rowvec2); d.rv_sb1, d.rv_sb2 = rv_strides
+    d.aux = _p(aux); d.ldaux = ldaux; d.aux_sb1, d.aux_sb2 = aux_strides
+    d.dropout_p = dropout_p; d.seed = seed
+    _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
+
+
+def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, ldo,
+                  q_off=0, k_off=0, v_off=0, dropout_p=0.0, seed=0):
+    _need_cuda(Q, K, V, O)
+    _lib.check(_lib.load().bmhrl_attention_fwd(Q.data_ptr() + 2 * q_off, ldq, K.data_ptr() + 2 * k_off, ldk,
+                                               V.data_ptr() + 2 * v_off, ldv, O.data_ptr(), ldo, row_max.data_ptr(),
+                                               row_sum.data_ptr(), _p(mask), mask_sb, mask_sq, B, H, Sq, Sk, dk, scale,
+                                               dropout_p, seed, stream()), "bmhrl_attention_fwd")
+
+
+def softmax_rows(S, lds, P, ldp, rows, cols):
+    _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr(), ldp, rows, cols, stream()), "bmhrl_softmax_rows")
+
+
+def attn_delta(dO, lddo, O, ldo, delta, B, H, Sq, dk):
+    _lib.check(_lib.load().bmhrl_attn_delta(dO.data_ptr(), lddo, O.data_ptr(), ldo, delta.data_ptr(), B, H, Sq, dk, stream()),
+               "bmhrl_attn_delta")
+
+
+def layernorm_fwd(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows, D):
+    _need_cuda(x)
+    _lib.check(_lib.load().bmhrl_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y_bf16), ldy, _p(y_f32),
+                                               _p(mean), _p(rstd), rows, D, stream()), "bmhrl_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, accumulate_dx, dgamma, dbeta, rows, D):
+    _lib.check(_lib.load().bmhrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dx.data_ptr(), int(accumulate_dx), _p(dgamma), _p(dbeta), rows, D, stream()),
+               "bmhrl_layernorm_bwd")
+
+
+def add_posenc(a, b, pe, out, out_bf16, ldob, B, S, D, dropout_p=0.0, seed=0):
+    _need_cuda(a)
+    _lib.check(_lib.load().bmhrl_add_posenc(a.data_ptr(), _p(b), pe.data_ptr(), out.data_ptr(), _p(out_bf16), ldob, B, S, D,
+                                            dropout_p, seed, stream()), "bmhrl_add_posenc")
+
+
+def embed_posenc(tok, tok2, mix, table, pe, emb_out, out, B, L, D, scale, dropout_p=0.0, seed=0):
+    _need_cuda(tok, table)
+    _lib.check(_lib.load().bmhrl_embed_posenc(tok.data_ptr(), _p(tok2), mix, table.data_ptr(), pe.data_ptr(), _p(emb_out),
+                                              out.data_ptr(), B, L, D, scale, dropout_p, seed, stream()), "bmhrl_embed_posenc")
+
+
+def embed_bwd(tok, tok2, mix, dC, dtable, B, L, D, scale):
+    _lib.check(_lib.load().bmhrl_embed_bwd(tok.data_ptr(), _p(tok2), mix, dC.data_ptr(), dtable.data_ptr(), B, L, D, scale,
+                                           stream()), "bmhrl_embed_bwd")
+
+
+def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_off=0):
+    _need_cuda(x, y)
+    _lib.check(_lib.load().bmhrl_cast_bf16(x.data_ptr(), ldx, y.data_ptr() + 2 * y_off, ldy, rows, cols, scale, dropout_p,
+                                           seed, stream()), "bmhrl_cast_bf16")
+
+
+def colsum_bf16(dY, ld, db, accumulate, rows, cols, dy_off=0, db_off=0):
+    _lib.check(_lib.load().bmhrl_colsum_bf16(dY.data_ptr() + 2 * dy_off, ld, db.data_ptr() + 4 * db_off, int(accumulate),
+                                             rows, cols, stream()), "bmhrl_colsum_bf16")
+
+
+def gate_fwd(cv, ca, a_v, out, out_bf16, ldob, rows, D):
+    _lib.check(_lib.load().bmhrl_gate_fwd(cv.data_ptr(), ca.data_ptr(), a_v.data_ptr(), out.data_ptr(), _p(out_bf16), ldob,
+                                          rows, D, stream()), "bmhrl_gate_fwd")
+
+
+def gate_bwd(dout, cv, ca, a_v, dcv, dca, da_v, rows, D):
+    _lib.check(_lib.load().bmhrl_gate_bwd(dout.data_ptr(), cv.data_ptr(), ca.data_ptr(), a_v.data_ptr(), dcv.data_ptr(),
+                                          dca.data_ptr(), _p(da_v), rows, D, stream()), "bmhrl_gate_bwd")
+
+
+def expand_goals_index(seg, src, B, L):
+    _lib.check(_lib.load().bmhrl_expand_goals_index(seg.data_ptr(), src.data_ptr(), B, L, stream()), "bmhrl_expand_goals_index")
+
+
+def gather_rows(x, src, out, out_bf16, ldob, rows, D):
+    _lib.check(_lib.load().bmhrl_gather_rows(x.data_ptr(), src.data_ptr(), out.data_ptr(), _p(out_bf16), ldob, rows, D,
+                                             stream()), "bmhrl_gather_rows")
+
+
+def scatter_add_rows(dout, src, dx, rows, D):
+    _lib.check(_lib.load().bmhrl_scatter_add_rows(dout.data_ptr(), src.data_ptr(), dx.data_ptr(), rows, D, stream()),
+               "bmhrl_scatter_add_rows")
+
+
+def log_softmax_(logits, ld, rows, V):
+    _lib.check(_lib.load().bmhrl_log_softmax(logits.data_ptr(), ld, rows, V, stream()), "bmhrl_log_softmax")
+
+
+def smooth_kl_fwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, row_loss, amp_out, rows, V):
+    _lib.check(_lib.load().bmhrl_smooth_kl_fwd(logp.data_ptr(), ld, trg.data_ptr(), _p(biased_trg), _p(score), _p(n_row),
+                                               smoothing, pad_idx, zero_pad_rows, row_loss.data_ptr(), _p(amp_out), rows, V,
+                                               stream()), "bmhrl_smooth_kl_fwd")
+
+
+def smooth_kl_bwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, g_bf16, ldg,
+                  g_f32, rows, V):
+    _lib.check(_lib.load().bmhrl_smooth_kl_bwd(logp.data_ptr(), ld, trg.data_ptr(), _p(biased_trg), _p(score), _p(n_row),
+                                               smoothing, pad_idx, zero_pad_rows, loss_scale.data_ptr(), _p(g_bf16), ldg,
+                                               _p(g_f32), rows, V, stream()), "bmhrl_smooth_kl_bwd")
+
+
+def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed):
+    _lib.check(_lib.load().bmhrl_sample_tokens(logp.data_ptr(), ld, out.data_ptr(), _p(p_out), rows, V, int(greedy), seed,
+                                               stream()), "bmhrl_sample_tokens")
+
+
+def reinforce_fwd(logp, ld, action, value, critic_value, row_policy, row_value, rows, V):
+    _lib.check(_lib.load().bmhrl_reinforce_fwd(logp.data_ptr(), ld, action.data_ptr(), value.data_ptr(),
+                                               critic_value.data_ptr(), row_policy.data_ptr(), row_value.data_ptr(), rows, V,
+                                               stream()), "bmhrl_reinforce_fwd")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _lib.check(_lib.load().bmhrl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, lr,
+                                           beta1, beta2, eps, weight_decay, step, grad_scale, stream()), "bmhrl_adam_step")

@@ -1,0 +1,185 @@
+/*
+ * bmhrl_hip.h -- C ABI of the MI355X (gfx950) hot path of Berghojo/bmhrl.
+ *
+ * The reference has no native code: its hot path is a chain of stock torch ops
+ * (model/multihead_attention.py, model/blocks.py, model/bm_hrl_agent.py, loss/,
+ * epoch_loops/captioning_bmrl_loops.py).  Each entry point below replaces one such chain
+ * and cites it.  All pointers are DEVICE pointers owned by the caller; nothing is
+ * allocated or freed inside; every call enqueues work on `stream` and returns
+ * immediately (0 = ok, negative = -errno style argument error, positive = hipError_t).
+ * No global mutable state: calls are re-entrant across processes (one process per GPU).
+ *
+ * bf16 tensors are passed as `void*` to 16-bit storage.  Every 2-D bf16 buffer has an
+ * explicit leading dimension (elements) that must be a multiple of 8; padding columns
+ * must hold finite values (the library never writes them; allocate zeroed).
+ */
+#ifndef BMHRL_HIP_H
+#define BMHRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bmhrl_stream_t; /* hipStream_t */
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched MFMA GEMM with fused epilogue:  C[b](M,N) = epilogue( sum_k A[b](m,k) * B[b](k,n) )
+ * Replaces nn.Linear forward/backward (model/multihead_attention.py:70-72,89; model/blocks.py:178-184;
+ * model/bm_hrl_agent.py:439,464) and the Q.K^T / P.V products of attention() backward
+ * (model/multihead_attention.py:13,25).  bf16 operands, fp32 accumulate.
+ *   a_trans = 0: A stored [M][K] (k contiguous, leading dim lda)   1: stored [K][M]
+ *   b_trans = 0: B stored [N][K] (k contiguous; nn.Linear weight)  1: stored [K][N]
+ *   batch index = b1 * batch2 + b2; element offset of operand X = b1 * x_sb1 + b2 * x_sb2.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+  BMHRL_EPI_LINEAR = 0, /* v = alpha*acc (+bias[n]) ; mask==0 -> -1e9 ; relu ; dropout ; (+residual[m][n]) */
+  BMHRL_EPI_PROB = 1,   /* p = exp(masked(alpha*acc) - rowvec[m]) / rowvec2[m]        (recompute softmax P) */
+  BMHRL_EPI_DSCORE = 2  /* ds = aux[m][n] * (acc - rowvec[m]) * alpha               (softmax backward)     */
+};
+
+typedef struct bmhrl_gemm_desc {
+  int32_t M, N, K;
+  int32_t batch1, batch2;
+  const void* A; int64_t lda, a_sb1, a_sb2; int32_t a_trans;
+  const void* B; int64_t ldb, b_sb1, b_sb2; int32_t b_trans;
+  float* C;  int64_t ldc, c_sb1, c_sb2;          /* fp32 output, may be NULL */
+  void* Cb;  int64_t ldcb, cb_sb1, cb_sb2;       /* bf16 output, may be NULL */
+  int32_t epilogue;
+  float alpha;
+  int32_t relu;
+  int32_t accumulate;                             /* C += v instead of C = v (fp32 output only) */
+  const float* bias;                              /* [N] or NULL */
+  const float* residual; int64_t ldr, r_sb1, r_sb2; /* fp32 [M][N] or NULL */
+  const uint8_t* mask; int64_t mask_sb1, mask_sm; /* byte mask[b1][m*mask_sm + n], mask_sm may be 0 */
+  const float* rowvec; const float* rowvec2; int64_t rv_sb1, rv_sb2; /* per-row fp32 vectors: (row max, row sum) or delta */
+  const void* aux; int64_t ldaux, aux_sb1, aux_sb2; /* bf16 [M][N] (P for DSCORE) */
+  float dropout_p; uint64_t seed;                 /* inverted dropout on v, element id = ((batch*M + m)*N + n) */
+} bmhrl_gemm_desc;
+
+int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused scaled-dot-product attention forward (flash style, S x S never materialised).
+ * Replaces attention() + the head split/merge views, model/multihead_attention.py:7-31,75-86:
+ *   O[b,q,h,:] = softmax_k( Q[b,q,h,:].K[b,k,h,:] * scale ; mask==0 -> -1e9 ) . V[b,k,h,:]
+ * Q,K,V,O are bf16 (B, S, H*DK) row-major with leading dims ldq/ldk/ldv/ldo (heads are column
+ * slices, exactly the .view(B,-1,H,d_k) of the reference).  DK must be 256 (the reference's
+ * d_model 1024 / H 4).  mask: bytes, mask[b*mask_sb + q*mask_sq + k], mask_sq = 0 for key-padding
+ * masks (B,1,Sk).  row_max / row_sum (B,H,Sq) fp32 = softmax statistics of the masked scaled scores, kept
+ * separately (not as one log-sum-exp) so that fully masked rows (all scores -1e9) stay exact in backward.
+ * dropout_p > 0 applies the reference's dropout on the attention OUTPUT (:27-28).
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                        void* O, int64_t ldo, float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
+                        int64_t mask_sq,
+                        int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t DK, float scale,
+                        float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+
+/* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
+ * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */
+int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
+                       bmhrl_stream_t stream);
+
+/* delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (softmax backward row term) */
+int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta,
+                     int32_t B, int32_t H, int32_t Sq, int32_t DK, bmhrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (eps 1e-5, affine) -- nn.LayerNorm inside ResidualConnection, model/blocks.py:132,138,
+ * and normCA/normCV, model/bm_hrl_agent.py:68-69,107-108.
+ *   fwd: x fp32 (rows, D) -> y bf16 (rows, ldy) and/or y32 fp32 (rows, D); saves mean, rstd.
+ *   bwd: dx (+)= LN'(dy) ; dgamma/dbeta accumulated with fp32 atomics into zeroed buffers.
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, int64_t ldy,
+                        float* y_f32, float* mean, float* rstd, int64_t rows, int32_t D, bmhrl_stream_t stream);
+int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        float* dx, int32_t accumulate_dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                        bmhrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Feature add + positional encoding (K1): out = a (+ b) + PE[s]  (epoch_loops/captioning_bmrl_loops.py:498,
+ * model/blocks.py:105-112).  pe is the precomputed fp32 table (S_max, D).  Optional bf16 copy and dropout.
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_add_posenc(const float* a, const float* b, const float* pe, float* out, void* out_bf16, int64_t ldob,
+                     int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+
+/* Embedding * sqrt(D) (+ second embedding mix) + PE : model/blocks.py:44-48, model/bm_hrl_agent.py:611-625,642.
+ * emb_out (B,L,D) fp32 = un-positional-encoded embeddings (critic input); out = emb_out + PE. */
+int bmhrl_embed_posenc(const int64_t* tok, const int64_t* tok2, float mix, const float* table, const float* pe,
+                       float* emb_out, float* out, int32_t B, int32_t L, int32_t D, float scale,
+                       float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+/* dTable[tok] += scale * (1-mix) * dC ; dTable[tok2] += scale * mix * dC  (fp32 atomics) */
+int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const float* dC, float* dtable,
+                    int32_t B, int32_t L, int32_t D, float scale, bmhrl_stream_t stream);
+
+/* fp32 -> bf16 cast of a (rows, cols) matrix into a padded-leading-dimension buffer, with optional scale
+ * and inverted dropout (regenerates the forward mask from seed: element id = row*cols + col). */
+int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
+                    float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+
+/* db[n] (+)= sum_m dY[m][n]  (bias gradient of nn.Linear), dY bf16 */
+int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t accumulate, int64_t rows, int32_t cols,
+                      bmhrl_stream_t stream);
+
+/* Fusion gate (K7): out = g*Cv + (1-g)*Ca, g = sigmoid(clamp(a,-2,2)), model/bm_hrl_agent.py:111-114 */
+int bmhrl_gate_fwd(const float* cv, const float* ca, const float* a_v, float* out, void* out_bf16, int64_t ldob,
+                   int64_t rows, int32_t D, bmhrl_stream_t stream);
+int bmhrl_gate_bwd(const float* dout, const float* cv, const float* ca, const float* a_v, float* dcv, float* dca,
+                   float* da_v /* atomic += */, int64_t rows, int32_t D, bmhrl_stream_t stream);
+
+/* Manager.expand_goals (K8), model/bm_hrl_agent.py:415-429: src[row] = row of goals_in copied to (b,l), or -1 = zero.
+ * bmhrl_expand_goals_index builds the (B*L) int32 source map from the segment labels with the reference's
+ * row-transition quirks; fwd is a gather, bwd a scatter-add. */
+int bmhrl_expand_goals_index(const int32_t* seg, int32_t* src, int32_t B, int32_t L, bmhrl_stream_t stream);
+int bmhrl_gather_rows(const float* x, const int32_t* src, float* out, void* out_bf16, int64_t ldob, int64_t rows,
+                      int32_t D, bmhrl_stream_t stream);
+int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, float* dx, int64_t rows, int32_t D,
+                           bmhrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-token loss step (K9-K11): log-softmax over the vocabulary fused with the loss.
+ *  bmhrl_log_softmax:   logits fp32 (rows, V) -> log-probs in place (WorkerCore, model/bm_hrl_agent.py:463-466)
+ *  bmhrl_smooth_kl_fwd: per-row sum of LabelSmoothing (biased_trg == NULL; loss/label_smoothing.py:12-32) or
+ *                       BiasedKL (loss/biased_kl.py:22-53) over the unreduced (rows, V) divergence, never
+ *                       materialising the target distribution; amp = clamp(score*p(a)*n_row, 0, 1) is computed
+ *                       here (epoch_loops/captioning_bmrl_loops.py:285,321-322,409-416).
+ *  bmhrl_smooth_kl_bwd: d(loss_scale * sum)/d logits -> bf16 (rows, ldg) incl. the path through amp.
+ *  zero_pad_rows: the reference's `idx.sum() > 0` guard decided on the host side (1 = zero pad rows).
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_log_softmax(float* logits, int64_t ld, int64_t rows, int32_t V, bmhrl_stream_t stream);
+int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
+                        const float* score, const float* n_row, float smoothing, int32_t pad_idx,
+                        int32_t zero_pad_rows, float* row_loss, float* amp_out, int64_t rows, int32_t V,
+                        bmhrl_stream_t stream);
+int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
+                        const float* score, const float* n_row, float smoothing, int32_t pad_idx,
+                        int32_t zero_pad_rows, const float* loss_scale /* device scalar */, void* dlogits_bf16,
+                        int64_t ldg, float* dlogits_f32, int64_t rows, int32_t V, bmhrl_stream_t stream);
+/* a ~ Categorical(exp(logp)) by inverse CDF with one uniform per row (counter RNG: seed, row);
+ * greedy != 0 -> argmax.  epoch_loops/captioning_bmrl_loops.py:283-284 */
+int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
+                        int32_t greedy, uint64_t seed, bmhrl_stream_t stream);
+/* Reinforce (loss/biased_kl.py:69-81): per-row terms of -adv*log(clamp(p(a))) and adv^2 */
+int bmhrl_reinforce_fwd(const float* logp, int64_t ld, const int64_t* action, const float* value,
+                        const float* critic_value, float* row_policy, float* row_value, int64_t rows, int32_t V,
+                        bmhrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser (K14): torch.optim.Adam semantics (scripts/train_rl_captioning_module.py:81-83, default
+ * betas/eps, L2 weight decay added to the gradient) over one flat fp32 bucket; grad_scale multiplies
+ * the gradient first (1/world for data parallel averaging).
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                    bmhrl_stream_t stream);
+
+/* Library self-description: returns the gfx target the kernels were built for ("gfx950"). */
+const char* bmhrl_hip_arch(void);
+int bmhrl_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMHRL_HIP_H */

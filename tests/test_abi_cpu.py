@@ -1,0 +1,33 @@
+"""CPU checks of the C-ABI boundary: the library builds, loads and exports every symbol include/bmhrl_hip.h declares."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bmhrl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bmhrl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from bmhrl_amd import build, _lib
+    build.build(verbose=False)
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 24
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/bmhrl_hip.h but not exported"
+    assert set(_lib.PROTOTYPES) | {"bmhrl_hip_arch", "bmhrl_hip_abi_version"} == set(syms)
+    assert lib.bmhrl_hip_arch() == b"gfx950"
+    assert lib.bmhrl_hip_abi_version() == 1
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from bmhrl_amd import ops
+    x = torch.zeros(4, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cast_bf16(x, 8, torch.zeros(4, 8, dtype=torch.bfloat16), 8, 4, 8)

@@ -1,0 +1,410 @@
+"""Kernel-level parity tests (GPU): each C-ABI entry point against a plain torch fp32/fp64 computation of the same
+op on bf16-rounded inputs, or against the CPU oracle for the losses.  Run with `pytest -m gpu` on an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import _lib
+    _lib.load()  # must exist: the product has no fallback
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b, floor=1e-6):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def padded(t, ld=None):
+    """copy a 2-D (or batched) bf16 tensor into a buffer whose last dim is padded to a multiple of 8"""
+    from bmhrl_amd.ops import pad8
+    ld = ld or pad8(t.shape[-1])
+    out = torch.zeros(*t.shape[:-1], ld, dtype=torch.bfloat16, device=t.device)
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (480, 300, 364), (4096, 1024, 1024), (100, 64, 300), (257, 513, 72), (1000, 10172 // 4, 364)])
+@pytest.mark.parametrize("a_trans,b_trans", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_layouts(dev, M, N, K, a_trans, b_trans):
+    from bmhrl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(dev)
+    Bm = bf(torch.randn(K, N, generator=g)).to(dev)  # logical (K, N), asymmetric random
+    ref = A.float() @ Bm.float()
+    As = padded(A.t().contiguous() if a_trans else A)
+    Bs = padded(Bm.contiguous() if b_trans else Bm.t().contiguous())
+    out = torch.full((M, N), float("nan"), device=dev)
+    outb = torch.zeros(M, ops.pad8(N), dtype=torch.bfloat16, device=dev)
+    ops.gemm(As, Bs, M, N, K, lda=As.shape[1], ldb=Bs.shape[1], a_trans=a_trans, b_trans=b_trans, C_f32=out, ldc=N,
+             C_bf16=outb, ldcb=outb.shape[1])
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 2e-5
+    assert rel_err(outb[:, :N].float(), ref) < 1e-2
+    assert float(outb[:, N:].float().abs().max()) == 0 if outb.shape[1] > N else True
+
+
+def test_gemm_linear_epilogue(dev):
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 480, 300, 1024
+    x = bf(torch.randn(M, K, generator=g)).to(dev)
+    w = bf(torch.randn(N, K, generator=g) / 32).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    out = torch.empty(M, N, device=dev)
+    ops.gemm(x, w, M, N, K, lda=K, ldb=K, C_f32=out, ldc=N, bias=bias, relu=True, residual=res, ldr=N, alpha=0.5)
+    ref = torch.relu(0.5 * (x.float() @ w.float().t()) + bias) + res
+    assert rel_err(out, ref) < 2e-5
+    out2 = out.clone()
+    ops.gemm(x, w, M, N, K, lda=K, ldb=K, C_f32=out2, ldc=N, accumulate=True)
+    assert rel_err(out2, out + x.float() @ w.float().t()) < 2e-5
+    # dropout: kept elements scaled by 1/(1-p), mask reproducible from the seed
+    d1 = torch.empty(M, N, device=dev); d2 = torch.empty(M, N, device=dev)
+    ops.gemm(x, w, M, N, K, lda=K, ldb=K, C_f32=d1, ldc=N, dropout_p=0.25, seed=77)
+    ops.gemm(x, w, M, N, K, lda=K, ldb=K, C_f32=d2, ldc=N, dropout_p=0.25, seed=77)
+    plain = x.float() @ w.float().t()
+    assert torch.equal(d1, d2)
+    keep = d1 != 0
+    assert 0.70 < float(keep.float().mean()) < 0.80
+    assert rel_err(d1[keep], plain[keep] / 0.75) < 2e-5
+
+
+def test_gemm_batched_attention_epilogues(dev):
+    """Q.K^T with PROB epilogue, dO.V^T with DSCORE epilogue, P^T.dO, dS.K  (the attention backward products)."""
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, H, Sq, Sk, dk = 2, 3, 37, 50, 64
+    D = H * dk
+    Q = bf(torch.randn(B, Sq, D, generator=g)).to(dev)
+    Kt = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    V = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    dO = bf(torch.randn(B, Sq, D, generator=g)).to(dev)
+    mask = torch.ones(B, Sk, dtype=torch.uint8)
+    mask[0, 45:] = 0
+    mask = mask.to(dev)
+    scale = 1 / math.sqrt(dk)
+    qh = Q.float().view(B, Sq, H, dk).transpose(1, 2)
+    kh = Kt.float().view(B, Sk, H, dk).transpose(1, 2)
+    vh = V.float().view(B, Sk, H, dk).transpose(1, 2)
+    doh = dO.float().view(B, Sq, H, dk).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    s = s.masked_fill(mask.view(B, 1, 1, Sk) == 0, -1e9)
+    m = s.max(-1).values
+    l = torch.exp(s - m[..., None]).sum(-1)
+    P_ref = torch.softmax(s, -1)
+    Skp = ops.pad8(Sk)
+    P = torch.zeros(B, H, Sq, Skp, dtype=torch.bfloat16, device=dev)
+    ops.gemm(Q, Kt, Sq, Sk, dk, lda=D, ldb=D, batch=(B, H), a_strides=(Sq * D, dk), b_strides=(Sk * D, dk), C_bf16=P,
+             ldcb=Skp, cb_strides=(H * Sq * Skp, Sq * Skp), epilogue=ops.EPI_PROB, alpha=scale, mask=mask, mask_sb1=Sk,
+             mask_sm=0, rowvec=m.contiguous(), rowvec2=l.contiguous(), rv_strides=(H * Sq, Sq))
+    assert rel_err(P[..., :Sk].float(), P_ref) < 1e-2
+    Pb = P[..., :Sk].float()
+    o = Pb @ vh
+    delta = (doh * o).sum(-1).contiguous()
+    dS = torch.zeros_like(P)
+    ops.gemm(dO, V, Sq, Sk, dk, lda=D, ldb=D, batch=(B, H), a_strides=(Sq * D, dk), b_strides=(Sk * D, dk), C_bf16=dS,
+             ldcb=Skp, cb_strides=(H * Sq * Skp, Sq * Skp), epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
+             rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=(H * Sq * Skp, Sq * Skp))
+    dS_ref = Pb * (doh @ vh.transpose(-1, -2) - delta[..., None]) * scale
+    assert rel_err(dS[..., :Sk].float(), dS_ref) < 1e-2
+    # dV = P^T dO  (both operands transposed: reduction runs over rows of P and dO)
+    dV = torch.empty(B, Sk, D, device=dev)
+    ops.gemm(P, dO, Sk, dk, Sq, lda=Skp, ldb=D, a_trans=True, b_trans=True, batch=(B, H),
+             a_strides=(H * Sq * Skp, Sq * Skp), b_strides=(Sq * D, dk), C_f32=dV, ldc=D, c_strides=(Sk * D, dk))
+    dV_ref = (Pb.transpose(-1, -2) @ doh).transpose(1, 2).reshape(B, Sk, D)
+    assert rel_err(dV, dV_ref) < 2e-5
+    # dQ = dS K  (B operand read transposed)
+    dQ = torch.empty(B, Sq, D, device=dev)
+    ops.gemm(dS, Kt, Sq, dk, Sk, lda=Skp, ldb=D, b_trans=True, batch=(B, H), a_strides=(H * Sq * Skp, Sq * Skp),
+             b_strides=(Sk * D, dk), C_f32=dQ, ldc=D, c_strides=(Sq * D, dk))
+    dQ_ref = (dS[..., :Sk].float() @ kh).transpose(1, 2).reshape(B, Sq, D)
+    assert rel_err(dQ, dQ_ref) < 2e-5
+
+
+def _attn_ref(Q, K, V, mask, H, scale):
+    B, Sq, D = Q.shape
+    Sk = K.shape[1]
+    dk = D // H
+    qh = Q.double().view(B, Sq, H, dk).transpose(1, 2)
+    kh = K.double().view(B, Sk, H, dk).transpose(1, 2)
+    vh = V.double().view(B, Sk, H, dk).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s.masked_fill(mask.view(B, 1, -1, Sk) == 0, -1e9)
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Sq, D), s
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,kind", [(2, 4, 64, 64, "none"), (2, 4, 70, 100, "pad"), (3, 2, 30, 37, "causal"),
+                                            (2, 4, 256, 800, "pad"), (2, 4, 800, 256, "pad"), (1, 4, 33, 130, "allmasked")])
+def test_attention_fwd(dev, B, H, Sq, Sk, kind):
+    from bmhrl_amd import ops
+    dk = 256
+    D = H * dk
+    g = torch.Generator().manual_seed(Sq * 1000 + Sk)
+    Q = bf(torch.randn(B, Sq, D, generator=g)).to(dev)
+    K = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    V = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    mask, sb, sq = None, 0, 0
+    if kind == "pad":
+        mask = torch.ones(B, 1, Sk, dtype=torch.uint8)
+        mask[0, 0, Sk - Sk // 3:] = 0
+        mask[-1, 0, 5:9] = 0
+        sb, sq = Sk, 0
+    elif kind == "causal":
+        mask = torch.tril(torch.ones(Sq, Sk, dtype=torch.uint8)).repeat(B, 1, 1)
+        mask[1, :, 20:] = 0
+        sb, sq = Sq * Sk, Sk
+    elif kind == "allmasked":
+        mask = torch.zeros(B, 1, Sk, dtype=torch.uint8)
+        sb, sq = Sk, 0
+    if mask is not None:
+        mask = mask.to(dev).contiguous()
+    O = torch.zeros(B, Sq, D, dtype=torch.bfloat16, device=dev)
+    rmax = torch.empty(B, H, Sq, device=dev)
+    rsum = torch.empty(B, H, Sq, device=dev)
+    scale = 1 / math.sqrt(dk)
+    # spike one key so the running max jumps in a late tile (forces the rescale branch)
+    K[0, Sk - 1] = K[0, Sk - 1] * 6
+    ops.attention_fwd(Q, K, V, O, rmax, rsum, mask, sb, sq, B, H, Sq, Sk, dk, scale, D, D, D, D)
+    torch.cuda.synchronize()
+    ref, s = _attn_ref(Q, K, V, mask, H, scale)
+    assert rel_err(O.float(), ref) < 1.5e-2  # bf16 P and bf16 output
+    m_ref = s.max(-1).values
+    l_ref = torch.exp(s - m_ref[..., None]).sum(-1)
+    assert rel_err(rmax, m_ref) < 1e-5
+    assert rel_err(rsum, l_ref) < 2e-3
+    if kind == "allmasked":  # uniform attention over all Sk keys (reference fills -1e9, not -inf)
+        assert rel_err(O.float(), V.float().view(B, Sk, D).mean(1, keepdim=True).expand(B, Sq, D)) < 1.5e-2
+
+
+def test_softmax_rows_and_delta(dev):
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    S = torch.randn(90, 37, generator=g).to(dev) * 3
+    S[5, 10:] = -1e9
+    P = torch.zeros(90, 40, dtype=torch.bfloat16, device=dev)
+    ops.softmax_rows(S, 37, P, 40, 90, 37)
+    assert rel_err(P[:, :37].float(), torch.softmax(S, -1)) < 1e-2
+    B, H, Sq, dk = 2, 2, 9, 64
+    dO = bf(torch.randn(B, Sq, H * dk, generator=g)).to(dev)
+    O = bf(torch.randn(B, Sq, H * dk, generator=g)).to(dev)
+    delta = torch.empty(B, H, Sq, device=dev)
+    ops.attn_delta(dO, H * dk, O, H * dk, delta, B, H, Sq, dk)
+    ref = (dO.float() * O.float()).view(B, Sq, H, dk).sum(-1).transpose(1, 2)
+    assert rel_err(delta, ref) < 1e-5
+
+
+@pytest.mark.parametrize("rows,D", [(4096, 1024), (12800, 128), (480, 300), (33, 20)])
+def test_layernorm(dev, rows, D):
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+    dy = torch.randn(rows, D, generator=g).to(dev)
+    yb = ops.bf16_zeros(rows, D, dev)
+    yf = torch.empty(rows, D, device=dev)
+    mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, yb, yb.shape[1], yf, mean, rstd, rows, D)
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    ref.backward(dy.double())
+    assert rel_err(yf, ref) < 1e-5
+    assert rel_err(yb[:, :D].float(), ref) < 1e-2
+    dx = torch.ones(rows, D, device=dev)
+    dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, True, dg, db, rows, D)
+    assert rel_err(dx - 1, xr.grad) < 2e-5
+    assert rel_err(dg, gr.grad) < 2e-5
+    assert rel_err(db, br.grad) < 2e-5
+
+
+def test_posenc_embed_cast_colsum(dev):
+    from bmhrl_amd import ops
+    from oracle.bmhrl_oracle import posenc_table
+    g = torch.Generator().manual_seed(4)
+    B, S, D = 3, 11, 20
+    pe = posenc_table(64, D).float().to(dev)
+    a = torch.rand(B, S, D, generator=g).to(dev); b = torch.rand(B, S, D, generator=g).to(dev)
+    out = torch.empty(B, S, D, device=dev)
+    ob = ops.bf16_zeros(B * S, D, dev)
+    ops.add_posenc(a, b, pe, out, ob, ob.shape[1], B, S, D)
+    ref = a + b + pe[:S].unsqueeze(0)
+    assert rel_err(out, ref) < 1e-6
+    assert rel_err(ob[:, :D].float().view(B, S, D), ref) < 1e-2
+    V = 17
+    table = torch.randn(V, D, generator=g).to(dev)
+    tok = torch.randint(0, V, (B, S), generator=g).to(dev); tok2 = torch.randint(0, V, (B, S), generator=g).to(dev)
+    emb = torch.empty(B, S, D, device=dev); out = torch.empty(B, S, D, device=dev)
+    sc = math.sqrt(D)
+    ops.embed_posenc(tok, tok2, 0.25, table, pe, emb, out, B, S, D, sc)
+    e_ref = table[tok] * sc * 0.75 + table[tok2] * sc * 0.25
+    assert rel_err(emb, e_ref) < 1e-6 and rel_err(out, e_ref + pe[:S]) < 1e-6
+    dC = torch.randn(B, S, D, generator=g).to(dev)
+    dt = torch.zeros(V, D, device=dev)
+    ops.embed_bwd(tok, tok2, 0.25, dC, dt, B, S, D, sc)
+    dref = torch.zeros(V, D, device=dev)
+    dref.index_add_(0, tok.reshape(-1), dC.reshape(-1, D) * sc * 0.75)
+    dref.index_add_(0, tok2.reshape(-1), dC.reshape(-1, D) * sc * 0.25)
+    assert rel_err(dt, dref) < 1e-5
+    x = torch.randn(500, 300, generator=g).to(dev)
+    y = ops.bf16_zeros(500, 300, dev)
+    ops.cast_bf16(x, 300, y, y.shape[1], 500, 300, 2.0)
+    assert torch.equal(y[:, :300], (x * 2).to(torch.bfloat16)) and float(y[:, 300:].float().abs().max()) == 0
+    db = torch.empty(300, device=dev)
+    ops.colsum_bf16(y, y.shape[1], db, False, 500, 300)
+    assert rel_err(db, y[:, :300].float().sum(0)) < 1e-5
+
+
+def test_gate_expand_gather(dev, golden):
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, D = 96, 20
+    cv = torch.randn(rows, D, generator=g).to(dev); ca = torch.randn(rows, D, generator=g).to(dev)
+    for a0 in (0.3, -2.5):
+        a = torch.tensor([a0], device=dev)
+        out = torch.empty(rows, D, device=dev)
+        ops.gate_fwd(cv, ca, a, out, None, 0, rows, D)
+        ar = a.clone().requires_grad_(True); cvr = cv.clone().requires_grad_(True); car = ca.clone().requires_grad_(True)
+        gt = torch.sigmoid(torch.clamp(ar, -2, 2))
+        ref = gt * cvr + (1 - gt) * car
+        assert rel_err(out, ref) < 1e-6
+        dout = torch.randn(rows, D, generator=g).to(dev)
+        ref.backward(dout)
+        dcv = torch.empty_like(cv); dca = torch.empty_like(ca); da = torch.zeros(1, device=dev)
+        ops.gate_bwd(dout, cv, ca, a, dcv, dca, da, rows, D)
+        assert rel_err(dcv, cvr.grad) < 1e-6 and rel_err(dca, car.grad) < 1e-6
+        assert abs(float(da) - float(ar.grad)) < 1e-4 * max(1.0, abs(float(ar.grad)))
+    k = golden("kat")
+    gin = torch.from_numpy(k["expand_in"]).to(dev); seg = torch.from_numpy(k["expand_seg"]).to(dev)
+    B, L, Dg = gin.shape
+    src = torch.empty(B * L, dtype=torch.int32, device=dev)
+    ops.expand_goals_index(seg.contiguous(), src, B, L)
+    out = torch.empty(B * L, Dg, device=dev)
+    ops.gather_rows(gin.reshape(B * L, Dg).contiguous(), src, out, None, 0, B * L, Dg)
+    assert np.array_equal(out.view(B, L, Dg).cpu().numpy(), k["expand_out"])
+    dx = torch.zeros(B * L, Dg, device=dev)
+    ops.scatter_add_rows(torch.ones(B * L, Dg, device=dev), src, dx, B * L, Dg)
+    exp = torch.zeros(B * L); s = src.cpu()
+    for i in range(B * L):
+        if s[i] >= 0:
+            exp[s[i]] += 1
+    assert torch.equal(dx[:, 0].cpu(), exp)
+    # random label patterns against the oracle's loop (incl. empty rows, row 0 empty, all empty)
+    from oracle.bmhrl_oracle import expand_goals
+    rg = np.random.default_rng(0)
+    for trial in range(20):
+        B, L = 6, 9
+        seg = torch.from_numpy((rg.random((B, L)) < [0.0, 0.1, 0.3, 0.5][trial % 4]).astype(np.int32))
+        if trial % 5 == 0:
+            seg[0] = 0
+        x = torch.randn(B, L, 3)
+        src = torch.empty(B * L, dtype=torch.int32, device=dev)
+        ops.expand_goals_index(seg.to(dev), src, B, L)
+        out = torch.empty(B * L, 3, device=dev)
+        ops.gather_rows(x.reshape(B * L, 3).to(dev), src, out, None, 0, B * L, 3)
+        assert torch.equal(out.cpu().view(B, L, 3), expand_goals(x, seg))
+
+
+def test_loss_kernels_vs_oracle(dev, golden):
+    from bmhrl_amd import ops
+    from oracle import bmhrl_oracle as O
+    g = golden("losses")
+    logits = torch.from_numpy(g["logits"]); trg = torch.from_numpy(g["trg"]); sampled = torch.from_numpy(g["sampled"])
+    score = torch.from_numpy(g["score"]); baseline = torch.from_numpy(g["baseline"])
+    B, S, V = logits.shape
+    rows = B * S
+    lp = logits.clone().to(dev).reshape(rows, V).contiguous()
+    ops.log_softmax_(lp, V, rows, V)
+    assert rel_err(lp, torch.log_softmax(logits, -1).reshape(rows, V)) < 1e-6
+    t = trg.reshape(-1).to(dev)
+    row_loss = torch.empty(rows, device=dev)
+    ops.smooth_kl_fwd(lp, V, t, None, None, None, 0.7, 1, -1, row_loss, None, rows, V)
+    assert rel_err(row_loss, torch.from_numpy(g["ls"]).sum(-1)) < 1e-5
+    n_tok = float((trg != 1).sum())
+    scale = torch.tensor([1.0 / n_tok], device=dev)
+    gf = torch.empty(rows, V, device=dev)
+    gb = ops.bf16_zeros(rows, V, dev)
+    ops.smooth_kl_bwd(lp, V, t, None, None, None, 0.7, 1, -1, scale, gb, gb.shape[1], gf, rows, V)
+    assert rel_err(gf, torch.from_numpy(g["ls_grad_logits"]).reshape(rows, V)) < 1e-5
+    assert rel_err(gb[:, :V].float(), gf) < 1e-2
+    a = sampled.reshape(-1).to(dev)
+    mask = (trg != 1)
+    n_row = mask.sum(-1, keepdim=True).expand(B, S).reshape(-1).float().to(dev)
+    for stab, tag in ((False, "raw"), (True, "stab")):
+        sc = ((score - baseline) * mask.float() if stab else score).reshape(-1).to(dev).contiguous()
+        amp = torch.empty(rows, device=dev)
+        ops.smooth_kl_fwd(lp, V, t, a, sc, n_row, 0.7, 1, -1, row_loss, amp, rows, V)
+        assert rel_err(amp, torch.from_numpy(g[f"bkl_{tag}_amp"]).reshape(-1)) < 1e-5
+        assert rel_err(row_loss, torch.from_numpy(g[f"bkl_{tag}"]).sum(-1)) < 1e-5
+        scale = torch.tensor([1.0 / (n_tok * 0.2)], device=dev)
+        ops.smooth_kl_bwd(lp, V, t, a, sc, n_row, 0.7, 1, -1, scale, None, 0, gf, rows, V)
+        assert rel_err(gf, torch.from_numpy(g[f"bkl_{tag}_grad_logits"]).reshape(rows, V)) < 1e-5
+    # the idx.sum()>0 guard (only padded flat index is 0)
+    k = golden("kat")
+    lp4 = torch.from_numpy(k["a4_lp"]).reshape(6, 6).to(dev).contiguous()
+    rl = torch.empty(6, device=dev)
+    ops.smooth_kl_fwd(lp4, 6, torch.tensor([1, 4, 2, 5, 3, 2], device=dev), None, None, None, 0.7, 1, -1, rl, None, 6, 6)
+    assert rel_err(rl, torch.from_numpy(k["a4_ls_guard"]).sum(-1)) < 1e-5
+    ops.smooth_kl_fwd(lp4, 6, torch.tensor([2, 4, 1, 5, 3, 2], device=dev), None, None, None, 0.7, 1, -1, rl, None, 6, 6)
+    assert rel_err(rl, torch.from_numpy(k["a4_ls"]).sum(-1)) < 1e-5
+    # reinforce terms
+    act = torch.tensor([2, 0, 3, 1, 3, 4], device=dev)
+    val = torch.tensor([.1, .2, .3, .4, .5, .6], device=dev); cv = torch.tensor([.3, .1, .0, .2, .2, .9], device=dev)
+    rp = torch.empty(6, device=dev); rv = torch.empty(6, device=dev)
+    ops.reinforce_fwd(lp4, 6, act, val, cv, rp, rv, 6, 6)
+    assert abs(float(rp.mean() + rv.mean()) - float(k["a4_reinforce"])) < 1e-6
+
+
+def test_sampling(dev):
+    from bmhrl_amd import ops
+    V, rows = 1000, 4096
+    logits = torch.zeros(rows, V)
+    logits[:, 7] = math.log(300.0)
+    logits[:, 500] = math.log(700.0)
+    logits[:, [i for i in range(V) if i not in (7, 500)]] = -30.0
+    lp = torch.log_softmax(logits, -1).to(dev).contiguous()
+    out = torch.empty(rows, dtype=torch.int64, device=dev); p = torch.empty(rows, device=dev)
+    ops.sample_tokens(lp, V, out, p, rows, V, False, 123)
+    f7 = float((out == 7).float().mean()); f500 = float((out == 500).float().mean())
+    assert abs(f7 - 0.3) < 0.03 and abs(f500 - 0.7) < 0.03
+    assert rel_err(p, torch.exp(lp[torch.arange(rows), out])) < 1e-6
+    out2 = torch.empty_like(out)
+    ops.sample_tokens(lp, V, out2, None, rows, V, False, 123)
+    assert torch.equal(out, out2)
+    lp2 = torch.log_softmax(torch.randn(64, 10172), -1).to(dev)
+    o3 = torch.empty(64, dtype=torch.int64, device=dev)
+    ops.sample_tokens(lp2, 10172, o3, None, 64, 10172, True, 0)
+    assert torch.equal(o3, lp2.argmax(-1))
+
+
+def test_adam_matches_torch(dev):
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    p0 = torch.randn(n, generator=g).to(dev)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=0.01)
+    p = p0.clone(); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g).to(dev)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step(p, grad, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    assert rel_err(p, ref.data) < 1e-6
