@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: caption-train steps/s of the BMHRL hot path on MI355X (BASELINE.json metric).
+
+A step = one warmstart training step of the bimodal transformer (forward, label-smoothing KL loss, backward,
+gradient all-reduce when N > 1, Adam) on one synthetic batch B=16 per GPU, Tv=256, Ta=800, L=30, V=10172, N=2 layers,
+d_model=1024, H=4, dropout 0.1 in train mode (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed
+region.  One process per GPU; for N > 1 launch with torch.distributed.run (RCCL all-reduce of the flat gradient bucket).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     -- the cross-modal attention kernel (V<-A: B16 H4 Sq256 Sk800 d_k256), algorithmic 4*B*Sq*Sk*D flops per
+                  launch / mean launch time measured here with HIP events on the launch stream, vs the 2.5 PFLOP/s
+                  dense bf16 MFMA peak,
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's arithmetic) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--tv", type=int, default=256)
+    ap.add_argument("--ta", type=int, default=800)
+    ap.add_argument("--len", type=int, default=30)
+    ap.add_argument("--vocab", type=int, default=10172)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--eager", action="store_true", help="launch kernels step by step instead of replaying the HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the bounded CPU-oracle sample")
+    return ap.parse_args()
+
+
+def attention_roofline(dev, B, H, Sq, Sk, iters=50):
+    """Mean launch time of the fused cross-modal attention kernel at the step's own shape, HIP events on torch's
+    current stream (the stream the kernel is launched on)."""
+    from bmhrl_amd import ops
+    dk, D = 256, H * 256
+    g = torch.Generator(device="cpu").manual_seed(0)
+    Q = torch.randn(B, Sq, D, generator=g).to(dev).to(torch.bfloat16)
+    K = torch.randn(B, Sk, D, generator=g).to(dev).to(torch.bfloat16)
+    V = torch.randn(B, Sk, D, generator=g).to(dev).to(torch.bfloat16)
+    mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=dev)
+    O = torch.empty(B, Sq, D, dtype=torch.bfloat16, device=dev)
+    rmax = torch.empty(B, H, Sq, device=dev)
+    rsum = torch.empty(B, H, Sq, device=dev)
+    run = lambda: ops.attention_fwd(Q, K, V, O, rmax, rsum, mask, Sk, 0, B, H, Sq, Sk, dk, dk ** -0.5, D, D, D, D)
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 4.0 * B * Sq * Sk * D
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel<2,2> (cross-modal V<-A)", "achieved": flops / sec / 1e12,
+            "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0, "traffic": None,
+            "launch_us": sec * 1e6, "flops_per_launch": flops,
+            "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}}
+
+
+def cpu_baseline(args):
+    """The oracle's warmstart step (forward + loss + backward + Adam) on the host cores, on a bounded sample: a batch
+    of --cpu-batch instead of B (cost is linear in B), one warm-up + two timed steps."""
+    from bmhrl_amd import synthetic as syn
+    from bmhrl_amd.model.bm_hrl_agent import agent_state_shapes
+    from oracle import bmhrl_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = syn.default_cfg(dout_p=0.0, rl_att_layers=args.layers)
+    Bc = max(2, min(args.cpu_batch, args.batch))
+    sd = syn.fill_state_dict(agent_state_shapes(cfg, args.vocab, with_critic=False), seed=0, clone_layers=True)
+    sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(cfg.d_model_caps, seed=1).items()})
+    skip = ("critic.", "manager_core.", "manager.core.")
+    params = [k for k in sd if not k.startswith(skip) and not (".feed_forward.fc" in k and "_fus." in k)]
+    for k in params:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    opt = torch.optim.Adam([sd[k] for k in params], lr=1e-4)
+    b = syn.synthetic_batch(Bc, args.tv, args.ta, args.len, args.vocab, seed=0)
+    cap = b["captions"]
+    trg_in, trg_y = cap[:, :-1], cap[:, 1:]
+    masks = O.make_masks(b["rgb"], b["audio"], trg_in, 1)
+
+    def one():
+        opt.zero_grad()
+        pred = O.agent_forward(sd, cfg, (b["rgb"] + b["flow"], b["audio"]), trg_in, masks)[0]
+        O.warmstart_loss(pred, trg_y, 0.7, 1).backward()
+        opt.step()
+
+    one()
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        one()
+    dt = (time.perf_counter() - t0) / n
+    steps_per_s = 1.0 / (dt * args.batch / Bc)
+    return {"value": steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle warmstart step (fwd+loss+bwd+Adam, fp32, torch CPU {torch.__version__}) at batch {Bc} of "
+                      f"{args.batch}, same shapes; 1 warm-up + {n} timed steps, {dt:.2f} s per sampled step; value scaled "
+                      f"linearly to B={args.batch}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from bmhrl_amd import _lib, synthetic as syn
+    from bmhrl_amd.train import CaptionTrainer
+    _lib.load()
+
+    cfg = syn.default_cfg(dout_p=args.dropout, rl_att_layers=args.layers)
+    trainer = CaptionTrainer(cfg, args.vocab, dev, lr=1e-4)
+    trainer.agent.train()
+    trainer.agent.set_inference_mode(True)
+    b = syn.synthetic_batch(args.batch, args.tv, args.ta, args.len, args.vocab, seed=rank)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    cap = b["captions"].to(dev)
+
+    use_graph = not args.eager
+    if use_graph:
+        trainer.capture(fs, cap, warmup=2)
+        step = lambda: trainer.replay()
+    else:
+        step = lambda: trainer.step(fs, cap)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_v = float(loss)
+
+    if rank == 0:
+        roof = attention_roofline(dev, args.batch, cfg.rl_att_heads, args.tv, args.ta)
+        cpu = None if args.no_cpu_baseline else cpu_baseline(args)
+        out = {
+            "metric": "caption-train steps/sec", "value": args.steps * world / elapsed, "unit": "steps/s (one step = one "
+            "B=16 batch on one GPU; whole-job aggregate over all GPUs)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BMHRL warmstart step (BASELINE configs[1]): B={args.batch}/GPU Tv={args.tv} Ta={args.ta} "
+                                   f"L={args.len} V={args.vocab} N={args.layers} d_model=1024 H=4 dropout={args.dropout}",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "launch": "hip-graph" if use_graph else "eager", "samples_per_s": args.steps * world * args.batch / elapsed},
+            "loss": loss_v, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("mask", ptr), ("mask_sb1", i64), ("mask_sm", i64),
         ("rowvec", ptr), ("rowvec2", ptr), ("rv_sb1", i64), ("rv_sb2", i64),
         ("aux", ptr), ("ldaux", i64), ("aux_sb1", i64), ("aux_sb2", i64),
-        ("dropout_p", f32), ("seed", u64),
+        ("dropout_p", f32), ("seed", u64), ("drop_sb1", i64), ("drop_sb2", i64), ("drop_sm", i64), ("seed_dev", ptr),
     ]
 
 
@@ -35,15 +35,15 @@ class GemmDesc(C.Structure):
 PROTOTYPES = {
     "bmhrl_gemm": [C.POINTER(GemmDesc), ptr],
     "bmhrl_attention_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, f32,
-                            f32, u64, ptr],
+                            f32, u64, ptr, ptr],
     "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, ptr],
-    "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, i32, i32, i32, i32, ptr],
+    "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
-    "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, i32, ptr, ptr, i64, i32, ptr],
-    "bmhrl_add_posenc": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, f32, u64, ptr],
-    "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr],
+    "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_add_posenc": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, f32, u64, ptr, ptr],
+    "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
-    "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr],
+    "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_colsum_bf16": [ptr, i64, ptr, i32, i64, i32, ptr],
     "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_gate_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
@@ -52,10 +52,11 @@ PROTOTYPES = {
     "bmhrl_scatter_add_rows": [ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_log_softmax": [ptr, i64, i64, i32, ptr],
     "bmhrl_smooth_kl_fwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, i32, ptr],
-    "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, ptr, i64, i32, ptr],
+    "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
+    "bmhrl_log_softmax_bwd": [ptr, ptr, i64, ptr, i64, i64, i32, ptr],
     "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr],
     "bmhrl_reinforce_fwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
-    "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, f32, ptr],
+    "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
 }
 
 _lib = None
@@ -70,6 +71,12 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m bmhrl_amd.build` (hipcc --offload-arch=gfx950). "
             "bmhrl_amd has no CPU fallback.")
+    # One HIP runtime per process: the stream handles passed in come from torch, so the library must bind to the
+    # libamdhip64 torch itself uses (same SONAME as /opt/rocm's; whichever loads first wins).  Load torch's first.
+    import torch
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

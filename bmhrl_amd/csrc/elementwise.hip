@@ -41,7 +41,7 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 constexpr int LN_MAXC = 16;
 __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-                              int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D,
+                              const float* __restrict__ dx_add, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D,
                               int rows_per_wave) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -73,8 +73,7 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
       if (c < D) {
         const float xh = (xr[c] - mu) * rs, g = dyr[c] * gamma[c];
         const float v = rs * (g - s1 - xh * s2);
-        float* d = dx + row * D + c;
-        *d = accumulate_dx ? (*d + v) : v;
+        dx[row * D + c] = dx_add ? dx_add[row * D + c] + v : v;
       }
     }
   }
@@ -91,7 +90,8 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
 // ------------------------------------------------------------------------------------------------ K1: add + posenc
 __global__ void add_posenc_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ pe,
                                   float* __restrict__ out, bf16_t* __restrict__ ob, long ldob, int S, int D, long total,
-                                  float p, uint64_t seed) {
+                                  float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % D;
     const long row = i / D;
@@ -105,7 +105,9 @@ __global__ void add_posenc_kernel(const float* __restrict__ a, const float* __re
 
 __global__ void embed_posenc_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ tok2, float mix,
                                     const float* __restrict__ table, const float* __restrict__ pe, float* __restrict__ emb,
-                                    float* __restrict__ out, int L, int D, long total, float scale, float p, uint64_t seed) {
+                                    float* __restrict__ out, int L, int D, long total, float scale, float p, uint64_t seed0,
+                                    const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % D;
     const long row = i / D;
@@ -136,7 +138,8 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t*
 
 // ------------------------------------------------------------------------------------------------ casts / sums
 __global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows,
-                                 int cols, float scale, float p, uint64_t seed) {
+                                 int cols, float scale, float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
   const long total = rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % cols;
@@ -241,7 +244,12 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ dout, const in
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                            float gscale) {
+                            float gscale, const int32_t* __restrict__ step_dev) {
+  if (step_dev) {  // step count lives on the device so a captured graph advances it between replays
+    const float st = (float)step_dev[0];
+    bc1 = 1.f - powf(b1, st);
+    bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
     const float pi = p[i];
@@ -274,7 +282,7 @@ extern "C" int bmhrl_layernorm_fwd(const float* x, const float* gamma, const flo
 }
 
 extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, float* dx, int32_t accumulate_dx, float* dgamma, float* dbeta,
+                                   const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
                                    int64_t rows, int32_t D, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 64 * LN_MAXC);
   // enough waves to fill the chip (2048+), at most 32 rows per wave so the atomics stay ~rows/32 per column
@@ -283,27 +291,28 @@ extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float*
   if (rpw > 32) rpw = 32;
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-  hipLaunchKernelGGL(ln_bwd_kernel, grid, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, accumulate_dx, dgamma, dbeta,
+  hipLaunchKernelGGL(ln_bwd_kernel, grid, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta,
                      (long)rows, D, rpw);
   return hip_status(hipGetLastError());
 }
 
 extern "C" int bmhrl_add_posenc(const float* a, const float* b, const float* pe, float* out, void* out_bf16, int64_t ldob,
-                                int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+                                int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(a && pe && out && B > 0 && S > 0 && D > 0);
   const long total = (long)B * S * D;
   hipLaunchKernelGGL(add_posenc_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), a, b, pe, out, (bf16_t*)out_bf16,
-                     (long)ldob, S, D, total, dropout_p, seed);
+                     (long)ldob, S, D, total, dropout_p, seed, seed_dev);
   return hip_status(hipGetLastError());
 }
 
 extern "C" int bmhrl_embed_posenc(const int64_t* tok, const int64_t* tok2, float mix, const float* table, const float* pe,
                                   float* emb_out, float* out, int32_t B, int32_t L, int32_t D, float scale,
-                                  float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+                                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(tok && table && pe && out && B > 0 && L > 0 && D > 0);
   const long total = (long)B * L * D;
   hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), tok, tok2, mix, table, pe,
-                     emb_out, out, L, D, total, scale, dropout_p, seed);
+                     emb_out, out, L, D, total, scale, dropout_p, seed, seed_dev);
   return hip_status(hipGetLastError());
 }
 
@@ -317,10 +326,10 @@ extern "C" int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mi
 }
 
 extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
-                               float dropout_p, uint64_t seed, bmhrl_stream_t stream) {
+                               float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y,
-                     (long)ldy, (long)rows, cols, scale, dropout_p, seed);
+                     (long)ldy, (long)rows, cols, scale, dropout_p, seed, seed_dev);
   return hip_status(hipGetLastError());
 }
 
@@ -379,13 +388,13 @@ extern "C" int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, flo
 }
 
 extern "C" int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
-                               bmhrl_stream_t stream) {
-  BMHRL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1);
+                               float beta1, float beta2, float eps, float weight_decay, int32_t step, const int32_t* step_dev,
+                               float grad_scale, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || step_dev));
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, S_(stream), param, grad, exp_avg, exp_avg_sq,
-                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+                     (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, step_dev);
   return hip_status(hipGetLastError());
 }
 

@@ -27,7 +27,7 @@ struct GemmArgs {
   const uint8_t* mask; long mask_sb1, mask_sm;
   const float* rowvec; const float* rowvec2; long rv_sb1, rv_sb2;
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
-  float dropout_p; uint64_t seed;
+  float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
   int tiles_m;
 };
 
@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
   // One explicit call per accumulator tile (a loop over acc[mi][ni] is too big for the unroller and would
   // push the accumulators to scratch).
+  const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
+  const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
   auto epi = [&](const f32x16& av, const int mi, const int ni) {
     const int n = n0 + wn * 32 * TN + ni * 32 + r32;
     const bool n_ok = n < p.N;
@@ -182,15 +184,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
           v = v * p.alpha + bias;
           if (Mg && !Mg[(long)m * p.mask_sm + n]) v = NEG_MASK;
           if (p.relu) v = fmaxf(v, 0.f);
-          if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, p.seed, ((uint64_t)bz * p.M + m) * p.N + n);
+          if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n);
           if (Rg) v += Rg[(long)m * p.ldr + n];
         } else if (p.epilogue == BMHRL_EPI_PROB) {
           v = v * p.alpha;
           if (Mg && !Mg[(long)m * p.mask_sm + n]) v = NEG_MASK;
           v = __expf(v - RVg[m]) / RV2g[m];
-        } else {  // BMHRL_EPI_DSCORE
+        } else if (p.epilogue == BMHRL_EPI_DSCORE) {
           const float pr = (float)AUXg[(long)m * p.ldaux + n];
           v = pr * (v - RVg[m]) * p.alpha;
+        } else {  // BMHRL_EPI_RELU_BWD
+          v = ((float)AUXg[(long)m * p.ldaux + n] > 0.f) ? v * p.alpha : 0.f;
         }
         if (Cg) {
           float* dst = Cg + (long)m * p.ldc + n;
@@ -232,9 +236,9 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0);
   BMHRL_CHECK_ARG(d->lda >= (d->a_trans ? ((d->M + 7) & ~7) : ((d->K + 7) & ~7)));
   BMHRL_CHECK_ARG(d->ldb >= (d->b_trans ? ((d->N + 7) & ~7) : ((d->K + 7) & ~7)));
-  BMHRL_CHECK_ARG(d->epilogue >= 0 && d->epilogue <= 2);
-  if (d->epilogue != BMHRL_EPI_LINEAR) BMHRL_CHECK_ARG(d->rowvec != nullptr);
-  if (d->epilogue == BMHRL_EPI_DSCORE) BMHRL_CHECK_ARG(d->aux != nullptr);
+  BMHRL_CHECK_ARG(d->epilogue >= 0 && d->epilogue <= 3);
+  if (d->epilogue == BMHRL_EPI_PROB || d->epilogue == BMHRL_EPI_DSCORE) BMHRL_CHECK_ARG(d->rowvec != nullptr);
+  if (d->epilogue == BMHRL_EPI_DSCORE || d->epilogue == BMHRL_EPI_RELU_BWD) BMHRL_CHECK_ARG(d->aux != nullptr);
   if (d->epilogue == BMHRL_EPI_PROB) BMHRL_CHECK_ARG(d->rowvec2 != nullptr);
   BMHRL_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f);
   GemmArgs a;
@@ -249,7 +253,11 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.mask = d->mask; a.mask_sb1 = d->mask_sb1; a.mask_sm = d->mask_sm;
   a.rowvec = d->rowvec; a.rowvec2 = d->rowvec2; a.rv_sb1 = d->rv_sb1; a.rv_sb2 = d->rv_sb2;
   a.aux = (const bf16_t*)d->aux; a.ldaux = d->ldaux; a.aux_sb1 = d->aux_sb1; a.aux_sb2 = d->aux_sb2;
-  a.dropout_p = d->dropout_p; a.seed = d->seed; a.tiles_m = 0;
+  a.dropout_p = d->dropout_p; a.seed = d->seed; a.seed_dev = d->seed_dev; a.tiles_m = 0;
+  a.drop_sb1 = d->drop_sb1; a.drop_sb2 = d->drop_sb2; a.drop_sm = d->drop_sm;
+  if (a.drop_sb1 == 0 && a.drop_sb2 == 0 && a.drop_sm == 0) {
+    a.drop_sm = d->N; a.drop_sb2 = (long)d->M * d->N; a.drop_sb1 = a.drop_sb2 * d->batch2;
+  }
   const int batch = d->batch1 * d->batch2;
   const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
   hipError_t e;

@@ -103,8 +103,8 @@ __global__ void smooth_kl_fwd_kernel(const float* __restrict__ logp, long ld, co
 __global__ void smooth_kl_bwd_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
                                      const int64_t* __restrict__ btrg, const float* __restrict__ score,
                                      const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
-                                     const float* __restrict__ loss_scale, bf16_t* __restrict__ gb, long ldg,
-                                     float* __restrict__ gf, long rows, int V) {
+                                     const float* __restrict__ loss_scale, int wrt_logits, bf16_t* __restrict__ gb,
+                                     long ldg, float* __restrict__ gf, long rows, int V) {
   const long row = blockIdx.x;
   const float* lp = logp + row * ld;
   float raw = 0.f;
@@ -127,14 +127,26 @@ __global__ void smooth_kl_bwd_kernel(const float* __restrict__ logp, long ld, co
   float dsum = (float)(V - ns) * d0 + T.at(T.t);
   if (T.pad != T.t) dsum += T.at(T.pad);
   if (T.a >= 0 && T.a != T.t && T.a != T.pad) dsum += T.at(T.a);
-  const float G = -dsum + extra_a;  // sum_v d rowloss / d logp_v
+  const float G = wrt_logits ? (-dsum + extra_a) : 0.f;  // sum_v d rowloss / d logp_v (log-softmax backward term)
   for (int c = threadIdx.x; c < V; c += blockDim.x) {
-    float g = -T.at(c) - __expf(lp[c]) * G;
+    float g = -T.at(c) - (wrt_logits ? __expf(lp[c]) * G : 0.f);
     if (c == T.a) g += extra_a;
     g *= scale;
     if (gb) gb[row * ldg + c] = (bf16_t)g;
     if (gf) gf[row * (long)V + c] = g;
   }
+}
+
+__global__ void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp, long ld,
+                                       bf16_t* __restrict__ gb, long ldg, int V) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* d = dlogp + row * ld;
+  const float* lp = logp + row * ld;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) s += d[c];
+  s = block_sum(s, red);
+  for (int c = threadIdx.x; c < V; c += blockDim.x) gb[row * ldg + c] = (bf16_t)(d[c] - __expf(lp[c]) * s);
 }
 
 // Inverse-CDF categorical sample with one uniform per row (or arg-max), block per row.
@@ -221,13 +233,21 @@ extern "C" int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t*
 
 extern "C" int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
                                    const float* score, const float* n_row, float smoothing, int32_t pad_idx,
-                                   int32_t zero_pad_rows, const float* loss_scale, void* dlogits_bf16, int64_t ldg,
-                                   float* dlogits_f32, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+                                   int32_t zero_pad_rows, const float* loss_scale, int32_t wrt_logits, void* dlogits_bf16,
+                                   int64_t ldg, float* dlogits_f32, int64_t rows, int32_t V, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(logp && trg && loss_scale && (dlogits_bf16 || dlogits_f32) && rows > 0 && V > 2);
   BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
   hipLaunchKernelGGL(smooth_kl_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
-                     score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, (bf16_t*)dlogits_bf16, (long)ldg,
-                     dlogits_f32, (long)rows, V);
+                     score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, wrt_logits, (bf16_t*)dlogits_bf16,
+                     (long)ldg, dlogits_f32, (long)rows, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, void* dlogits_bf16, int64_t ldg,
+                                     int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dlogp && logp && dlogits_bf16 && rows > 0 && V > 0 && ld >= V && ldg >= V);
+  hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), dlogp, logp, (long)ld,
+                     (bf16_t*)dlogits_bf16, (long)ldg, V);
   return hip_status(hipGetLastError());
 }
 

@@ -1,0 +1,644 @@
+"""Autograd building blocks of the bimodal transformer, each a coarse torch.autograd.Function whose forward and
+backward are sequences of C-ABI kernel launches (bmhrl_amd.ops).  Only fp32 "stream" tensors and parameters cross
+the autograd boundary; bf16 operands, softmax statistics and dropout seeds stay inside a block.
+
+Precision plan (north_star: logits within 1e-3 relative): residual streams, LayerNorm / softmax statistics, the
+vocabulary logits and all reductions are fp32; GEMM and attention operands are bf16 with fp32 MFMA accumulation.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Optional
+
+import torch
+
+from . import ops
+from .ops import pad8
+
+_BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------ parameter shadows
+class ShadowCache:
+    """bf16 copies (row stride padded to 8) of fp32 weights and concatenated fp32 biases, refreshed when a
+    parameter's version counter moves (optimizer step, load_state_dict) or the cache is invalidated."""
+
+    def __init__(self):
+        self.w = {}
+        self.b = {}
+        self.epoch = 0
+
+    def invalidate(self):
+        self.epoch += 1
+
+    @staticmethod
+    def _alive(ent, params):
+        return ent is not None and all(r() is p for r, p in zip(ent[2], params))
+
+    def _version(self, params):
+        return (self.epoch,) + tuple(p._version for p in params) + (params[0].device,)
+
+    def weight(self, *params):
+        key = tuple(id(p) for p in params)
+        ver = self._version(params)
+        ent = self.w.get(key)
+        if not self._alive(ent, params):   # id() of a freed parameter can be reused by a new one
+            ent = None
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        K = params[0].shape[1]
+        N = sum(p.shape[0] for p in params)
+        buf = ent[1] if ent is not None and ent[1].device == params[0].device else ops.bf16_zeros(N, K, params[0].device)
+        ld = buf.shape[1]
+        off = 0
+        for p in params:
+            ops.cast_bf16(p.detach(), K, buf, ld, p.shape[0], K, y_off=off * ld)
+            off += p.shape[0]
+        self.w[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+        return buf
+
+    def bias(self, *params):
+        if len(params) == 1:
+            return params[0].detach()
+        key = tuple(id(p) for p in params)
+        ver = self._version(params)
+        ent = self.b.get(key)
+        if self._alive(ent, params) and ent[0] == ver:
+            return ent[1]
+        buf = torch.cat([p.detach() for p in params])
+        self.b[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+        return buf
+
+
+SHADOWS = ShadowCache()
+
+
+class DropoutSeeds:
+    """Per-site dropout seeds.  Every site draws `base + counter`; under graph replay the device word `dev`
+    (incremented inside the captured step) is added by the kernels so masks differ between replays."""
+
+    def __init__(self, base: int = 0x5EED):
+        self.base = base
+        self.counter = 0
+        self.dev: Optional[torch.Tensor] = None
+
+    def next(self) -> int:
+        self.counter += 1
+        return (self.base * 0x9E3779B97F4A7C15 + self.counter * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+
+
+SEEDS = DropoutSeeds()
+
+
+def _mask_u8(mask: Optional[torch.Tensor]):
+    """(B,1,Sk) or (B,Sq,Sk) bool/byte mask -> contiguous byte tensor + (batch stride, row stride)."""
+    if mask is None:
+        return None, 0, 0
+    m = mask
+    if m.dtype != torch.bool and m.dtype != torch.uint8:
+        m = m != 0
+    m = m.contiguous()
+    B, R, Sk = m.shape
+    return m, R * Sk, (Sk if R > 1 else 0)
+
+
+# ------------------------------------------------------------------------------------------------ attention core
+def _use_flash(dk: int, Sq: int) -> bool:
+    return dk == 256 and Sq >= 128
+
+
+def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, msq, B, H, Sq, Sk, dk, p_drop, seed):
+    """Returns (O bf16 [B*Sq, H*dk] with the reference's output dropout applied, stats) where stats is
+    ('flash', row_max, row_sum) or ('mat', P bf16 [B,H,Sq,Skp])."""
+    dev = Qb.device
+    D = H * dk
+    scale = 1.0 / math.sqrt(dk)
+    O = torch.empty(B * Sq, D, dtype=_BF16, device=dev)
+    if _use_flash(dk, Sq):
+        rmax = torch.empty(B, H, Sq, device=dev)
+        rsum = torch.empty(B, H, Sq, device=dev)
+        ops.attention_fwd(Qb, Kb, Vb, O, rmax, rsum, mask, msb, msq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, D,
+                          q_off=q_off, k_off=k_off, v_off=v_off, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+        return O, ("flash", rmax, rsum)
+    Skp = pad8(Sk)
+    S = torch.empty(B, H, Sq, Sk, device=dev)
+    ops.gemm(Qb, Kb, Sq, Sk, dk, lda=ldq, ldb=ldk, a_off=q_off, b_off=k_off, batch=(B, H), a_strides=(Sq * ldq, dk),
+             b_strides=(Sk * ldk, dk), C_f32=S, ldc=Sk, c_strides=(H * Sq * Sk, Sq * Sk), alpha=scale, mask=mask,
+             mask_sb1=msb, mask_sm=msq)
+    P = torch.zeros(B, H, Sq, Skp, dtype=_BF16, device=dev)
+    ops.softmax_rows(S, Sk, P, Skp, B * H * Sq, Sk)
+    ops.gemm(P, Vb, Sq, dk, Sk, lda=Skp, ldb=ldv, b_off=v_off, b_trans=True, batch=(B, H),
+             a_strides=(H * Sq * Skp, Sq * Skp), b_strides=(Sk * ldv, dk), C_bf16=O, ldcb=D, cb_strides=(Sq * D, dk),
+             dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev, drop_strides=(Sq * D, dk, D))
+    return O, ("mat", P)
+
+
+def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, dQb, dq_off, lddq, dKb, dk_off, lddk,
+                   dVb, dv_off, lddv, mask, msb, msq, B, H, Sq, Sk, dk, p_drop):
+    """dOb: gradient w.r.t. the PRE-dropout attention output (bf16 [B*Sq, D]); Ob: saved post-dropout output.
+    Writes bf16 dQ/dK/dV into column slices of the given buffers."""
+    dev = dOb.device
+    D = H * dk
+    scale = 1.0 / math.sqrt(dk)
+    Skp = pad8(Sk)
+    delta = torch.empty(B, H, Sq, device=dev)
+    # sum_d dO_pre * O_pre == (1-p) * sum_d dO_pre * O_post   (both carry the same keep mask / scale)
+    ops.attn_delta(dOb, D, Ob, D, delta, B, H, Sq, dk, scale=1.0 - p_drop)
+    pstr = (H * Sq * Skp, Sq * Skp)
+    if stats[0] == "flash":
+        P = torch.zeros(B, H, Sq, Skp, dtype=_BF16, device=dev) if Skp != Sk else torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)
+        ops.gemm(Qb, Kb, Sq, Sk, dk, lda=ldq, ldb=ldk, a_off=q_off, b_off=k_off, batch=(B, H), a_strides=(Sq * ldq, dk),
+                 b_strides=(Sk * ldk, dk), C_bf16=P, ldcb=Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
+                 mask=mask, mask_sb1=msb, mask_sm=msq, rowvec=stats[1], rowvec2=stats[2], rv_strides=(H * Sq, Sq))
+    else:
+        P = stats[1]
+    dS = torch.zeros(B, H, Sq, Skp, dtype=_BF16, device=dev) if Skp != Sk else torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)
+    ops.gemm(dOb, Vb, Sq, Sk, dk, lda=D, ldb=ldv, b_off=v_off, batch=(B, H), a_strides=(Sq * D, dk),
+             b_strides=(Sk * ldv, dk), C_bf16=dS, ldcb=Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale,
+             rowvec=delta, rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=pstr)
+    # dV = P^T dO ; dK = dS^T Q ; dQ = dS K
+    ops.gemm(P, dOb, Sk, dk, Sq, lda=Skp, ldb=D, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,
+             b_strides=(Sq * D, dk), C_bf16=dVb, ldcb=lddv, cb_off=dv_off, cb_strides=(Sk * lddv, dk))
+    ops.gemm(dS, Qb, Sk, dk, Sq, lda=Skp, ldb=ldq, b_off=q_off, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,
+             b_strides=(Sq * ldq, dk), C_bf16=dKb, ldcb=lddk, cb_off=dk_off, cb_strides=(Sk * lddk, dk))
+    ops.gemm(dS, Kb, Sq, dk, Sk, lda=Skp, ldb=ldk, b_off=k_off, b_trans=True, batch=(B, H), a_strides=pstr,
+             b_strides=(Sk * ldk, dk), C_bf16=dQb, ldcb=lddq, cb_off=dq_off, cb_strides=(Sq * lddq, dk))
+
+
+# ------------------------------------------------------------------------------------------------ linear helpers
+def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx, dx_f32=None, dx_bf16=None, lddxb=0,
+                dx_epilogue=ops.EPI_LINEAR, dx_alpha=1.0, dx_aux=None, ldaux=0, dx_drop=0.0, dx_seed=0,
+                dy_off=0, x_off=0, w_off=0, dx_accumulate=False):
+    """Gradients of y = x W^T + b given dy (bf16 [rows, N] at dy_off, leading dim ldy).
+    dW (fp32 [N, K]) = dy^T x ; db = column sums of dy ; dx = dy W (fp32 and/or bf16, optional fused epilogue)."""
+    dev = dyb.device
+    dw = db = None
+    if need_dw:
+        dw = torch.empty(N, K, device=dev)
+        ops.gemm(dyb, xb, N, K, rows, lda=ldy, ldb=ldx, a_off=dy_off, b_off=x_off, a_trans=True, b_trans=True, C_f32=dw, ldc=K)
+    if need_db:
+        db = torch.empty(N, device=dev)
+        ops.colsum_bf16(dyb, ldy, db, False, rows, N, dy_off=dy_off)
+    if need_dx:
+        ops.gemm(dyb, wb, rows, K, N, lda=ldy, ldb=wb.shape[1], a_off=dy_off, b_off=w_off, b_trans=True, C_f32=dx_f32,
+                 ldc=K, C_bf16=dx_bf16, ldcb=lddxb, epilogue=dx_epilogue, alpha=dx_alpha, aux=dx_aux, ldaux=ldaux,
+                 dropout_p=dx_drop, seed=dx_seed, seed_dev=SEEDS.dev, accumulate=dx_accumulate)
+    return dw, db
+
+
+class MHAFn(torch.autograd.Function):
+    """[x +] dropout( d2Q( attention( Q2d(LN?(x)), K2d(kv), V2d(kv), mask ) ) )
+
+    model/multihead_attention.py:60-92 wrapped (optionally) by model/blocks.py:135-144.  Self attention
+    (kv_in is None): keys/values come from the same (normalised) tensor and Q/K/V run as one [3D, dq] GEMM.
+    Cross attention: kv_in is the OTHER stream, un-normalised (model/bm_hrl_agent.py:362-364, 91-94).
+    """
+
+    @staticmethod
+    def forward(ctx, x, kv_in, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop, residual):
+        dev = x.device
+        B, Sq, dq = x.shape
+        D = wq.shape[0]
+        dk = D // H
+        rows_q = B * Sq
+        x = x.contiguous()
+        self_att = kv_in is None
+        has_ln = ln_w is not None
+        ldx = pad8(dq)
+        xb = ops.bf16_zeros(rows_q, dq, dev)
+        mean = rstd = None
+        if has_ln:
+            mean = torch.empty(rows_q, device=dev)
+            rstd = torch.empty(rows_q, device=dev)
+            ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), xb, ldx, None, mean, rstd, rows_q, dq)
+        else:
+            ops.cast_bf16(x, dq, xb, ldx, rows_q, dq)
+        m8, msb, msq = _mask_u8(mask)
+        s_attn, s_res = SEEDS.next(), SEEDS.next()
+        if self_att:
+            Sk, rows_k, dkv = Sq, rows_q, dq
+            w_qkv = SHADOWS.weight(wq, wk, wv)
+            b_qkv = SHADOWS.bias(bq, bk, bv)
+            QKV = torch.empty(rows_q, 3 * D, dtype=_BF16, device=dev)
+            ops.gemm(xb, w_qkv, rows_q, 3 * D, dq, lda=ldx, ldb=w_qkv.shape[1], C_bf16=QKV, ldcb=3 * D, bias=b_qkv)
+            Qb = Kb = Vb = QKV
+            q_off, k_off, v_off, ldq, ldk = 0, D, 2 * D, 3 * D, 3 * D
+            kvb = None
+        else:
+            _, Sk, dkv = kv_in.shape
+            rows_k = B * Sk
+            kv_in = kv_in.contiguous()
+            kvb = ops.bf16_zeros(rows_k, dkv, dev)
+            ops.cast_bf16(kv_in, dkv, kvb, kvb.shape[1], rows_k, dkv)
+            w_q = SHADOWS.weight(wq)
+            w_kv = SHADOWS.weight(wk, wv)
+            Qb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
+            KV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
+            ops.gemm(xb, w_q, rows_q, D, dq, lda=ldx, ldb=w_q.shape[1], C_bf16=Qb, ldcb=D, bias=bq.detach())
+            ops.gemm(kvb, w_kv, rows_k, 2 * D, dkv, lda=kvb.shape[1], ldb=w_kv.shape[1], C_bf16=KV, ldcb=2 * D,
+                     bias=SHADOWS.bias(bk, bv))
+            Kb = Vb = KV
+            q_off, k_off, v_off, ldq, ldk = 0, 0, D, D, 2 * D
+        Ob, stats = _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldk, m8, msb, msq, B, H, Sq, Sk, dk, p_drop, s_attn)
+        w_o = SHADOWS.weight(wo)
+        y = torch.empty(B, Sq, dq, device=dev)
+        ops.gemm(Ob, w_o, rows_q, dq, D, lda=D, ldb=w_o.shape[1], C_f32=y, ldc=dq, bias=bo.detach(),
+                 residual=x if residual else None, ldr=dq, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        ctx.save_for_backward(x, ln_w, mean, rstd, xb, kvb, Qb, Kb, Ob, m8, *stats[1:], wq, wk, wv, wo)
+        ctx.cfg = (B, H, Sq, Sk, dq, dkv, D, dk, p_drop, residual, self_att, has_ln, stats[0], msb, msq, s_attn, s_res,
+                   q_off, k_off, v_off, ldq, ldk)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, H, Sq, Sk, dq, dkv, D, dk, p_drop, residual, self_att, has_ln, kind, msb, msq, s_attn, s_res, q_off, k_off, v_off,
+         ldq, ldk) = ctx.cfg
+        saved = ctx.saved_tensors
+        x, ln_w, mean, rstd, xb, kvb, Qb, Kb, Ob, m8 = saved[:10]
+        n_stats = 2 if kind == "flash" else 1
+        stats = (kind,) + tuple(saved[10:10 + n_stats])
+        wq, wk, wv, wo = saved[10 + n_stats:]
+        Vb = Kb
+        dev = dy.device
+        rows_q, rows_k = B * Sq, B * Sk
+        ldx = pad8(dq)
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        # d(out) through the residual-branch dropout -> bf16
+        dyb = ops.bf16_zeros(rows_q, dq, dev)
+        ops.cast_bf16(dy, dq, dyb, ldx, rows_q, dq, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        # linear_d2Q backward; its dx is d(attention output), taken back through the output dropout in the epilogue
+        dOb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
+        w_o = SHADOWS.weight(wo)
+        dwo, dbo = _linear_bwd(dyb, ldx, rows_q, dq, Ob, D, D, w_o, need_dw=need[10], need_db=need[11], need_dx=True,
+                               dx_bf16=dOb, lddxb=D, dx_drop=p_drop, dx_seed=s_attn)
+        del keep
+        if self_att:
+            dQKV = torch.empty(rows_q, 3 * D, dtype=_BF16, device=dev)
+            dQb = dKb = dVb = dQKV
+            lddq = lddk = 3 * D
+        else:
+            dQb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
+            dKV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
+            dKb = dVb = dKV
+            lddq, lddk = D, 2 * D
+        _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldk, dQb, q_off, lddq, dKb, k_off, lddk,
+                       dVb, v_off, lddk, m8, msb, msq, B, H, Sq, Sk, dk, p_drop)
+        dxn = torch.empty(rows_q, dq, device=dev) if (need[0] or (has_ln and (need[2] or need[3]))) else None
+        dwq = dbq = dwk = dbk = dwv = dbv = dkv_in = None
+        if self_att:
+            w_qkv = SHADOWS.weight(wq, wk, wv)
+            need_w = need[4] or need[6] or need[8]
+            need_b = need[5] or need[7] or need[9]
+            dw, db = _linear_bwd(dQKV, 3 * D, rows_q, 3 * D, xb, ldx, dq, w_qkv, need_dw=need_w, need_db=need_b,
+                                 need_dx=dxn is not None, dx_f32=dxn)
+            if dw is not None:
+                dwq, dwk, dwv = dw[:D], dw[D:2 * D], dw[2 * D:]
+            if db is not None:
+                dbq, dbk, dbv = db[:D], db[D:2 * D], db[2 * D:]
+        else:
+            w_q = SHADOWS.weight(wq)
+            w_kv = SHADOWS.weight(wk, wv)
+            dwq, dbq = _linear_bwd(dQb, D, rows_q, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=need[5],
+                                   need_dx=dxn is not None, dx_f32=dxn)
+            if need[1]:
+                dkv_in = torch.empty(B, Sk, dkv, device=dev)
+            dw, db = _linear_bwd(dKV, 2 * D, rows_k, 2 * D, kvb, kvb.shape[1], dkv, w_kv, need_dw=need[6] or need[8],
+                                 need_db=need[7] or need[9], need_dx=need[1], dx_f32=dkv_in)
+            if dw is not None:
+                dwk, dwv = dw[:D], dw[D:]
+            if db is not None:
+                dbk, dbv = db[:D], db[D:]
+        dx = dlnw = dlnb = None
+        if has_ln:
+            if dxn is not None:
+                dx = torch.empty(B, Sq, dq, device=dev)
+                dlnw = torch.zeros(dq, device=dev) if need[2] else None
+                dlnb = torch.zeros(dq, device=dev) if need[3] else None
+                ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy if residual else None, dlnw, dlnb, rows_q, dq)
+        elif need[0]:
+            dx = dxn.view(B, Sq, dq)
+            if residual:
+                dx = dx + dy
+        return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None)
+
+
+class FFNFn(torch.autograd.Function):
+    """x + dropout( fc2( dropout( relu( fc1( LN(x) ) ) ) ) ) -- model/blocks.py:135-144 around :175-187."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, p_drop):
+        dev = x.device
+        B, S, d = x.shape
+        rows = B * S
+        dff = w1.shape[0]
+        x = x.contiguous()
+        ldx = pad8(d)
+        xb = ops.bf16_zeros(rows, d, dev)
+        mean = torch.empty(rows, device=dev)
+        rstd = torch.empty(rows, device=dev)
+        ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), xb, ldx, None, mean, rstd, rows, d)
+        s_in, s_res = SEEDS.next(), SEEDS.next()
+        wb1, wb2 = SHADOWS.weight(w1), SHADOWS.weight(w2)
+        hb = ops.bf16_zeros(rows, dff, dev)
+        ops.gemm(xb, wb1, rows, dff, d, lda=ldx, ldb=wb1.shape[1], C_bf16=hb, ldcb=hb.shape[1], bias=b1.detach(), relu=True,
+                 dropout_p=p_drop, seed=s_in, seed_dev=SEEDS.dev)
+        y = torch.empty(B, S, d, device=dev)
+        ops.gemm(hb, wb2, rows, d, dff, lda=hb.shape[1], ldb=wb2.shape[1], C_f32=y, ldc=d, bias=b2.detach(), residual=x, ldr=d,
+                 dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        ctx.save_for_backward(x, ln_w, mean, rstd, xb, hb, w1, w2)
+        ctx.cfg = (B, S, d, dff, p_drop, s_in, s_res)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, d, dff, p_drop, s_in, s_res = ctx.cfg
+        x, ln_w, mean, rstd, xb, hb, w1, w2 = ctx.saved_tensors
+        dev = dy.device
+        rows = B * S
+        ldx = pad8(d)
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        dyb = ops.bf16_zeros(rows, d, dev)
+        ops.cast_bf16(dy, d, dyb, ldx, rows, d, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        wb1, wb2 = SHADOWS.weight(w1), SHADOWS.weight(w2)
+        # dz = (dy W2) * [h > 0] / (1-p): h already carries relu and the inner dropout mask
+        dzb = ops.bf16_zeros(rows, dff, dev)
+        keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        dw2, db2 = _linear_bwd(dyb, ldx, rows, d, hb, hb.shape[1], dff, wb2, need_dw=need[5], need_db=need[6], need_dx=True,
+                               dx_bf16=dzb, lddxb=dzb.shape[1], dx_epilogue=ops.EPI_RELU_BWD, dx_alpha=keep, dx_aux=hb,
+                               ldaux=hb.shape[1])
+        dxn = torch.empty(rows, d, device=dev)
+        dw1, db1 = _linear_bwd(dzb, dzb.shape[1], rows, dff, xb, ldx, d, wb1, need_dw=need[3], need_db=need[4], need_dx=True,
+                               dx_f32=dxn)
+        dx = torch.empty(B, S, d, device=dev)
+        dlnw = torch.zeros(d, device=dev) if need[1] else None
+        dlnb = torch.zeros(d, device=dev) if need[2] else None
+        ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy, dlnw, dlnb, rows, d)
+        return dx, dlnw, dlnb, dw1, db1, dw2, db2, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = dropout(relu?(x W^T + b)) for fp32 activations (bf16 operands inside).  Small layers: Manager.linear,
+    value heads (model/bm_hrl_agent.py:439,259-260)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, p_drop):
+        dev = x.device
+        shp = x.shape
+        K = shp[-1]
+        rows = x.numel() // K
+        N = w.shape[0]
+        x2 = x.contiguous().view(rows, K)
+        xb = ops.bf16_zeros(rows, K, dev)
+        ops.cast_bf16(x2, K, xb, xb.shape[1], rows, K)
+        wb = SHADOWS.weight(w)
+        y = torch.empty(rows, N, device=dev)
+        seed = SEEDS.next()
+        ops.gemm(xb, wb, rows, N, K, lda=xb.shape[1], ldb=wb.shape[1], C_f32=y, ldc=N, bias=None if b is None else b.detach(),
+                 relu=relu, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+        ctx.save_for_backward(xb, w, y if (relu or p_drop > 0) else None)
+        ctx.cfg = (shp, rows, N, K, relu, p_drop, seed, b is not None)
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shp, rows, N, K, relu, p_drop, seed, has_b = ctx.cfg
+        xb, w, y = ctx.saved_tensors
+        dev = dy.device
+        need = ctx.needs_input_grad
+        dy2 = dy.contiguous().view(rows, N)
+        if y is not None:
+            # y = relu(z) * keep-mask: gradient passes where y != 0 with the same 1/(1-p) factor
+            keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+            dy2 = torch.where(y != 0, dy2 * keep, torch.zeros_like(dy2)) if relu else None
+            if dy2 is None:
+                dy2 = dy.contiguous().view(rows, N)
+        dyb = ops.bf16_zeros(rows, N, dev)
+        drop = p_drop if not relu else 0.0
+        ops.cast_bf16(dy2, N, dyb, dyb.shape[1], rows, N, dropout_p=drop, seed=seed, seed_dev=SEEDS.dev)
+        wb = SHADOWS.weight(w)
+        dx = torch.empty(rows, K, device=dev) if need[0] else None
+        dw, db = _linear_bwd(dyb, dyb.shape[1], rows, N, xb, xb.shape[1], K, wb, need_dw=need[1], need_db=has_b and need[2],
+                             need_dx=need[0], dx_f32=dx)
+        return (dx.view(shp) if dx is not None else None), dw, db, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """fp32 LayerNorm (normCA / normCV, model/bm_hrl_agent.py:107-108)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        dev = x.device
+        D = x.shape[-1]
+        rows = x.numel() // D
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=dev)
+        rstd = torch.empty(rows, device=dev)
+        ops.layernorm_fwd(x, w.detach(), b.detach(), None, 0, y, mean, rstd, rows, D)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x)
+        dw = torch.zeros(D, device=x.device) if need[1] else None
+        db = torch.zeros(D, device=x.device) if need[2] else None
+        ops.layernorm_bwd(dy.contiguous(), x, w, mean, rstd, dx, None, dw, db, rows, D)
+        return dx, dw, db
+
+
+class GateFn(torch.autograd.Function):
+    """g*Cv + (1-g)*Ca, g = sigmoid(clamp(a_v, -2, 2)) -- model/bm_hrl_agent.py:111-114."""
+
+    @staticmethod
+    def forward(ctx, cv, ca, a_v):
+        D = cv.shape[-1]
+        rows = cv.numel() // D
+        cv, ca = cv.contiguous(), ca.contiguous()
+        out = torch.empty_like(cv)
+        ops.gate_fwd(cv, ca, a_v.detach(), out, None, 0, rows, D)
+        ctx.save_for_backward(cv, ca, a_v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cv, ca, a_v = ctx.saved_tensors
+        D = cv.shape[-1]
+        rows = cv.numel() // D
+        dcv, dca = torch.empty_like(cv), torch.empty_like(ca)
+        da = torch.zeros(1, device=cv.device)
+        ops.gate_bwd(dout.contiguous(), cv, ca, a_v, dcv, dca, da, rows, D)
+        return dcv, dca, da
+
+
+class EmbedFn(torch.autograd.Function):
+    """(emb(y)*(1-f) + emb(yhat)*f) * sqrt(d) and the same + PE (dropout on the second output only).
+    model/blocks.py:44-48,105-112; model/bm_hrl_agent.py:611-625,642.  Output 0 feeds the critic (no grad)."""
+
+    @staticmethod
+    def forward(ctx, table, tok, tok2, mix, pe, p_drop):
+        B, L = tok.shape
+        D = table.shape[1]
+        dev = table.device
+        emb = torch.empty(B, L, D, device=dev)
+        out = torch.empty(B, L, D, device=dev)
+        seed = SEEDS.next()
+        tok = tok.contiguous()
+        tok2 = tok2.contiguous() if tok2 is not None else None
+        ops.embed_posenc(tok, tok2, float(mix), table.detach(), pe, emb, out, B, L, D, math.sqrt(D), p_drop, seed, SEEDS.dev)
+        ctx.save_for_backward(tok, tok2)
+        ctx.cfg = (B, L, D, float(mix), p_drop, seed, table.shape[0])
+        ctx.mark_non_differentiable(emb)
+        return emb, out
+
+    @staticmethod
+    def backward(ctx, _demb, dout):
+        B, L, D, mix, p_drop, seed, V = ctx.cfg
+        tok, tok2 = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None
+        dev = dout.device
+        dout = dout.contiguous()
+        if p_drop > 0:
+            # regenerate the forward mask: cast kernel applies it, then back to fp32 rows for the scatter
+            tmp = ops.bf16_zeros(B * L, D, dev)
+            ops.cast_bf16(dout, D, tmp, tmp.shape[1], B * L, D, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+            dout = tmp[:, :D].float().contiguous()
+        dtable = torch.zeros(V, D, device=dev)
+        ops.embed_bwd(tok, tok2, mix, dout, dtable, B, L, D, math.sqrt(D))
+        return dtable, None, None, None, None, None
+
+
+class ExpandGoalsFn(torch.autograd.Function):
+    """Manager.expand_goals (model/bm_hrl_agent.py:415-429) as gather / scatter-add over a precomputed row map."""
+
+    @staticmethod
+    def forward(ctx, goals, seg):
+        B, L, D = goals.shape
+        dev = goals.device
+        seg2 = seg.reshape(B, L).to(torch.int32).contiguous()
+        src = torch.empty(B * L, dtype=torch.int32, device=dev)
+        ops.expand_goals_index(seg2, src, B, L)
+        out = torch.empty(B, L, D, device=dev)
+        ops.gather_rows(goals.contiguous(), src, out, None, 0, B * L, D)
+        ctx.save_for_backward(src)
+        ctx.cfg = (B, L, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, L, D = ctx.cfg
+        (src,) = ctx.saved_tensors
+        dx = torch.zeros(B, L, D, device=dout.device)
+        ops.scatter_add_rows(dout.contiguous(), src, dx, B * L, D)
+        return dx, None
+
+
+class WorkerHeadFn(torch.autograd.Function):
+    """log_softmax( Linear_{(d_in+d_goal) -> V}( cat[x, goal_completion] ) ) -- model/bm_hrl_agent.py:483-484,463-466.
+    The concatenation only exists as the bf16 GEMM operand; logits / log-probs stay fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gc, w, b):
+        dev = x.device
+        B, L, d1 = x.shape
+        d2 = gc.shape[-1]
+        rows, K, V = B * L, d1 + d2, w.shape[0]
+        xb = ops.bf16_zeros(rows, K, dev)
+        ld = xb.shape[1]
+        ops.cast_bf16(x.contiguous(), d1, xb, ld, rows, d1)
+        ops.cast_bf16(gc.contiguous(), d2, xb, ld, rows, d2, y_off=d1)
+        wb = SHADOWS.weight(w)
+        logp = torch.empty(B, L, V, device=dev)
+        ops.gemm(xb, wb, rows, V, K, lda=ld, ldb=wb.shape[1], C_f32=logp, ldc=V, bias=b.detach())
+        ops.log_softmax_(logp, V, rows, V)
+        ctx.save_for_backward(xb, w, logp)
+        ctx.cfg = (B, L, d1, d2, V)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        B, L, d1, d2, V = ctx.cfg
+        xb, w, logp = ctx.saved_tensors
+        dev = dlogp.device
+        rows, K = B * L, d1 + d2
+        need = ctx.needs_input_grad
+        gb = ops.bf16_zeros(rows, V, dev)
+        ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
+        wb = SHADOWS.weight(w)
+        dcat = torch.empty(rows, K, device=dev) if (need[0] or need[1]) else None
+        dw, db = _linear_bwd(gb, gb.shape[1], rows, V, xb, xb.shape[1], K, wb, need_dw=need[2], need_db=need[3],
+                             need_dx=dcat is not None, dx_f32=dcat)
+        dx = dgc = None
+        if dcat is not None:
+            dcat = dcat.view(B, L, K)
+            dx, dgc = dcat[..., :d1], dcat[..., d1:]
+        return dx, dgc, dw, db
+
+
+class PosEncFn(torch.autograd.Function):
+    """a (+ b) + PE[:S] with dropout (K1: rgb + flow + PE, audio + PE).  The features are leaf inputs without
+    gradients in the reference's loops; a gradient is still passed through (scaled by the keep mask)."""
+
+    @staticmethod
+    def forward(ctx, a, b, pe, p_drop):
+        B, S, D = a.shape
+        out = torch.empty(B, S, D, device=a.device)
+        seed = SEEDS.next()
+        ops.add_posenc(a.contiguous(), None if b is None else b.contiguous(), pe, out, None, 0, B, S, D, p_drop, seed, SEEDS.dev)
+        ctx.cfg = (B, S, D, p_drop, seed, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, D, p_drop, seed, has_b = ctx.cfg
+        g = dout
+        if p_drop > 0:
+            tmp = ops.bf16_zeros(B * S, D, dout.device)
+            ops.cast_bf16(dout.contiguous(), D, tmp, tmp.shape[1], B * S, D, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+            g = tmp[:, :D].float().view(B, S, D)
+        return g, (g if has_b else None), None, None
+
+
+class SmoothKLFn(torch.autograd.Function):
+    """Unreduced-sum form of LabelSmoothing / BiasedKL: returns the per-row sums (B*S,) of the (B*S, V) divergence
+    and differentiates w.r.t. the log-probs (incl. the amplitude path).  loss/label_smoothing.py:12-32,
+    loss/biased_kl.py:22-53, epoch_loops/captioning_bmrl_loops.py:285,321-322."""
+
+    @staticmethod
+    def forward(ctx, logp, trg, biased_trg, score, n_row, smoothing, pad_idx):
+        B, S, V = logp.shape
+        rows = B * S
+        dev = logp.device
+        logp = logp.contiguous()
+        trg = trg.contiguous().view(-1)
+        bt = biased_trg.contiguous().view(-1) if biased_trg is not None else None
+        sc = score.contiguous().view(-1).float() if score is not None else None
+        nr = n_row.contiguous().view(-1).float() if n_row is not None else None
+        row_loss = torch.empty(rows, device=dev)
+        amp = torch.empty(rows, device=dev) if bt is not None else None
+        ops.smooth_kl_fwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, row_loss, amp, rows, V)
+        ctx.save_for_backward(logp, trg, bt, sc, nr)
+        ctx.cfg = (B, S, V, smoothing, pad_idx)
+        ctx.mark_non_differentiable(amp) if amp is not None else None
+        return row_loss, amp
+
+    @staticmethod
+    def backward(ctx, drow, _damp):
+        B, S, V, smoothing, pad_idx = ctx.cfg
+        logp, trg, bt, sc, nr = ctx.saved_tensors
+        rows = B * S
+        dev = logp.device
+        one = torch.ones(1, device=dev)
+        g = torch.empty(rows, V, device=dev)
+        ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, one, None, 0, g, rows, V, wrt_logits=False)
+        g = g * drow.contiguous().view(rows, 1)
+        return g.view(B, S, V), None, None, None, None, None, None

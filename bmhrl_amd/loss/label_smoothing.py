@@ -1,0 +1,20 @@
+"""LabelSmoothing with the reference's constructor and call signature (loss/label_smoothing.py:5-32).
+
+The reference returns the unreduced (B*S, V) divergence and every caller immediately sums it
+(epoch_loops/captioning_bmrl_loops.py:1158, :211).  The fused kernel never materialises the target distribution:
+this module returns the (B*S, 1) row sums, so `torch.sum(criterion(pred, trg))` is unchanged."""
+import torch.nn as nn
+
+from ..functional import SmoothKLFn
+
+
+class LabelSmoothing(nn.Module):
+
+    def __init__(self, smoothing, pad_idx):
+        super().__init__()
+        self.smoothing = smoothing
+        self.pad_idx = pad_idx
+
+    def forward(self, pred, target):  # pred (B, S, V) log-probs, target (B, S)
+        rows, _ = SmoothKLFn.apply(pred, target, None, None, None, float(self.smoothing), int(self.pad_idx))
+        return rows.unsqueeze(-1)

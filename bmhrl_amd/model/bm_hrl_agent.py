@@ -1,0 +1,377 @@
+"""BMHrlAgent and its parts with the reference's public surface (model/bm_hrl_agent.py): same constructor
+(`cfg`, `train_dataset`), `forward / warmstart / inference / teach_* / set_inference_mode / save_model / load_model`,
+attribute names and the 307-key state-dict layout, so reference checkpoints load and the reference's driver
+(scripts/train_rl_captioning_module.py) can construct it unchanged.  All arithmetic of the bimodal encoder, the two
+fusion stacks, manager and worker runs in the gfx950 HIP kernels (bmhrl_amd.functional).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..functional import ExpandGoalsFn, GateFn, LayerNormFn, LinearFn, WorkerHeadFn
+from .blocks import LayerStack, PositionalEncoder, PositionwiseFeedForward, ResidualConnection, VocabularyEmbedder, clone
+from .multihead_attention import MultiheadedAttention
+
+
+class AReLU(nn.Module):
+    """reference model/bm_hrl_agent.py:13-23"""
+
+    def __init__(self, alpha=0.90, beta=2.0):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.tensor([alpha]))
+        self.beta = nn.Parameter(torch.tensor([beta]))
+
+    def forward(self, x):
+        return F.relu(x) * (1 + torch.sigmoid(self.beta)) - F.relu(-x) * torch.clamp(self.alpha, min=0.01, max=0.99)
+
+
+class ModelBase(nn.Module):
+    """reference :26-37 -- checkpoint = plain state_dict at <dir>/<name>.pt"""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def save_model(self, checkpoint_dir):
+        torch.save(self.state_dict(), checkpoint_dir + f"/{self.name}.pt")
+
+    def load_model(self, checkpoint_dir):
+        self.load_state_dict(torch.load(checkpoint_dir + f"/{self.name}.pt"))
+
+
+class BMEncoderLayer(nn.Module):
+    """reference :328-384.  Three pre-norm residual blocks per modality: self attention, cross attention whose
+    keys/values are the OTHER stream after its self-attention block (un-normalised), feed forward."""
+
+    def __init__(self, d_model_M1, d_model_M2, d_model, d_ff_M1, d_ff_M2, dout_p, H):
+        super().__init__()
+        self.self_att_M1 = MultiheadedAttention(d_model_M1, d_model_M1, d_model_M1, H, dout_p, d_model)
+        self.self_att_M2 = MultiheadedAttention(d_model_M2, d_model_M2, d_model_M2, H, dout_p, d_model)
+        self.bi_modal_att_M1 = MultiheadedAttention(d_model_M1, d_model_M2, d_model_M2, H, dout_p, d_model)
+        self.bi_modal_att_M2 = MultiheadedAttention(d_model_M2, d_model_M1, d_model_M1, H, dout_p, d_model)
+        self.feed_forward_M1 = PositionwiseFeedForward(d_model_M1, d_ff_M1, dout_p)
+        self.feed_forward_M2 = PositionwiseFeedForward(d_model_M2, d_ff_M2, dout_p)
+        self.res_layers_M1 = clone(ResidualConnection(d_model_M1, dout_p), 3)
+        self.res_layers_M2 = clone(ResidualConnection(d_model_M2, dout_p), 3)
+
+    def forward(self, x, masks):
+        M1, M2 = x
+        M1_mask, M2_mask = masks
+        M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
+        M2 = self.self_att_M2.fused(M2, None, M2_mask, self.res_layers_M2[0].norm, residual=True)
+        M1m2 = self.bi_modal_att_M1.fused(M1, M2, M2_mask, self.res_layers_M1[1].norm, residual=True)
+        M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
+        M1m2 = self.feed_forward_M1.fused(M1m2, self.res_layers_M1[2].norm)
+        M2m1 = self.feed_forward_M2.fused(M2m1, self.res_layers_M2[2].norm)
+        return M1m2, M2m1
+
+
+class BMEncoder(nn.Module):
+    """reference :218-235"""
+
+    def __init__(self, d_model_M1, d_model_M2, d_model, d_ff_M1, d_ff_M2, dout_p, H, N):
+        super().__init__()
+        self.encoder = LayerStack(BMEncoderLayer(d_model_M1, d_model_M2, d_model, d_ff_M1, d_ff_M2, dout_p, H), N)
+
+    def forward(self, x, masks):
+        V, A = x
+        return self.encoder((V, A), (masks['V_mask'], masks['A_mask']))
+
+
+class BMFusionLayer(nn.Module):
+    """reference :54-117.  `feed_forward` is constructed (state-dict keys) but never applied, as in the reference."""
+
+    def __init__(self, d_model_A, d_model_V, d_model_C, d_model, d_ff_c, dout_p, H):
+        super().__init__()
+        self.res_layer_self_att = ResidualConnection(d_model_C, dout_p)
+        self.self_att = MultiheadedAttention(d_model_C, d_model_C, d_model_C, H, dout_p, d_model)
+        self.res_layer_enc_att_A = ResidualConnection(d_model_C, dout_p)
+        self.res_layer_enc_att_V = ResidualConnection(d_model_C, dout_p)
+        self.enc_att_A = MultiheadedAttention(d_model_C, d_model_A, d_model_A, H, dout_p, d_model)
+        self.enc_att_V = MultiheadedAttention(d_model_C, d_model_V, d_model_V, H, dout_p, d_model)
+        self.feed_forward = PositionwiseFeedForward(d_model_C, d_ff_c, dout_p)
+        self.normCA = nn.LayerNorm(d_model_C)
+        self.normCV = nn.LayerNorm(d_model_C)
+        self.a_v_constant = nn.Parameter(torch.tensor([0.0]))
+
+    def forward(self, x, masks):
+        C, memory = x
+        Av, Va = memory
+        C = self.self_att.fused(C, None, masks['C_mask'], self.res_layer_self_att.norm, residual=True)
+        Ca = self.enc_att_A.fused(C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, residual=True)
+        Cv = self.enc_att_V.fused(C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, residual=True)
+        Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
+        Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
+        return GateFn.apply(Cv, Ca, self.a_v_constant), memory
+
+
+class BMFusion(nn.Module):
+    """reference :120-130"""
+
+    def __init__(self, d_model_A, d_model_V, d_model_C, d_model, d_ff_c, dout_p, H, N):
+        super().__init__()
+        self.decoder = LayerStack(BMFusionLayer(d_model_A, d_model_V, d_model_C, d_model, d_ff_c, dout_p, H), N)
+
+    def forward(self, x, masks):
+        C, _ = self.decoder(x, masks)
+        return C
+
+
+class SegmentCritic(nn.Module):
+    """Frozen LSTM(4) -> AReLU -> GRU(2) -> AReLU -> Linear segment scorer, reference :186-215.
+    Runs under no_grad on torch's RNN kernels (not on the north-star kernel list).
+    `cfg.rl_critic_path` is loaded when given; None leaves the (frozen) default initialisation in place."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.name = "SegmentCritic"
+        d = cfg.d_model_caps
+        self.lstm = nn.LSTM(d, 2 * d, num_layers=4, batch_first=True)
+        self.gru = nn.GRU(2 * d, 2 * d, num_layers=2, batch_first=True)
+        self.lin = nn.Linear(2 * d, 1)
+        self.relu = AReLU()
+        self.relu2 = AReLU()
+        for p in self.parameters():
+            p.requires_grad = False
+        path = getattr(cfg, "rl_critic_path", None)
+        if path is not None:
+            self.load_state_dict(torch.load(path))
+
+    def forward(self, emb):
+        with torch.no_grad():
+            h, _ = self.lstm(emb)
+            h, _ = self.gru(self.relu(h))
+            return self.lin(self.relu2(h))
+
+
+class LinearCore(nn.Module):
+    """reference :387-396 (registered for its state-dict keys; Manager.forward does not use it, :438)"""
+
+    def __init__(self, d_model_caps, d_goal, dout_p):
+        super().__init__()
+        self.linear = nn.Linear(d_model_caps, d_goal)
+        self.dropout = nn.Dropout(dout_p)
+
+
+class Manager(nn.Module):
+    """reference :399-454: goals = expand_goals(dropout(linear(feat)) [+ exploration noise], segment labels)"""
+
+    def __init__(self, device, d_model_caps, d_goal, dout_p, core=None, exploration=True):
+        super().__init__()
+        self.device = device
+        self.core = core if core is not None else LinearCore(d_model_caps, d_goal, dout_p)
+        self.linear = nn.Linear(d_model_caps, d_goal)
+        self.dropout = nn.Dropout(dout_p)
+        self.dout_p = dout_p
+        self.exploration = exploration
+        self.d_goal = d_goal
+        self.mean_factor = 10
+        self.std_factor = 5
+
+    def forward(self, x, critic_mask):
+        p = self.dout_p if self.training else 0.0
+        g = LinearFn.apply(x, self.linear.weight, self.linear.bias, False, p)
+        if self.exploration:
+            # one (d_goal,) Gaussian vector N(mean/10, std/5) - 0.5*mean/10 for all tokens (reference :444-452)
+            with torch.no_grad():
+                mean = torch.nanmean(g)
+                std = torch.sqrt(torch.nanmean((g - mean).abs() ** 2)) / self.std_factor
+                mean = mean / self.mean_factor
+                noise = torch.randn(self.d_goal, device=g.device) * std + mean - 0.5 * mean
+            g = g + noise
+        return ExpandGoalsFn.apply(g, critic_mask)
+
+
+class WorkerCore(nn.Module):
+    """reference :456-466"""
+
+    def __init__(self, voc_size, d_in, d_goal):
+        super().__init__()
+        self.projection = nn.Linear(d_in + d_goal, voc_size)
+
+
+class Worker(nn.Module):
+    """reference :468-487: log_softmax(projection(cat[x, goal_attention(goal, x, x)]))"""
+
+    def __init__(self, voc_size, d_in, d_goal, dout_p, d_model, core=None):
+        super().__init__()
+        self.core = core if core is not None else WorkerCore(voc_size, d_in, d_goal)
+        self.goal_attention = MultiheadedAttention(d_goal, d_in, d_in, 2, dout_p, d_model)
+
+    def forward(self, x, goal, mask):
+        gc = self.goal_attention.fused(goal, x, mask)
+        return WorkerHeadFn.apply(x, gc, self.core.projection.weight, self.core.projection.bias)
+
+
+def _value_head(ffn: PositionwiseFeedForward, projection: nn.Linear, feat):
+    p = ffn.dout_p if ffn.training else 0.0
+    h = LinearFn.apply(feat, ffn.fc1.weight, ffn.fc1.bias, True, p)
+    h = LinearFn.apply(h, ffn.fc2.weight, ffn.fc2.bias, True, 0.0)   # fc2, then the head's ReLU
+    return LinearFn.apply(h, projection.weight, projection.bias, False, 0.0)
+
+
+class BMWorkerValueFunction(ModelBase):
+    """reference :251-269: Linear(relu(FFN(worker_feat))); the goal input is ignored."""
+
+    def __init__(self, cfg):
+        super().__init__("bm_worker_value_function")
+        d = cfg.d_model_caps
+        self.value_function = PositionwiseFeedForward(d, d * 2, cfg.dout_p)
+        self.projection = nn.Linear(d, 1)
+        self.activation = nn.ReLU()
+
+    def forward(self, x):
+        w_feat, _ = x
+        return _value_head(self.value_function, self.projection, w_feat)
+
+
+class BMManagerValueFunction(ModelBase):
+    """reference :272-286"""
+
+    def __init__(self, cfg):
+        super().__init__("bm_manager_value_function")
+        d = cfg.d_model_caps
+        self.value_function = PositionwiseFeedForward(d, d * 2, cfg.dout_p)
+        self.projection = nn.Linear(d, 1)
+        self.activation = nn.ReLU()
+
+    def forward(self, x):
+        return _value_head(self.value_function, self.projection, x)
+
+
+class BMHrlAgent(nn.Module):
+    """reference :491-661"""
+
+    def __init__(self, cfg, train_dataset):
+        super().__init__()
+        self.name = "bm_hrl_agent"
+        self.d_video, self.d_audio = cfg.d_vid, cfg.d_aud
+        self.d_proj = getattr(cfg, "rl_projection_d", None)
+        self.d_model_caps, self.d_model = cfg.d_model_caps, cfg.d_model
+        self.att_heads, self.att_layers = cfg.rl_att_heads, cfg.rl_att_layers
+        self.dout_p = cfg.dout_p
+        self.d_goal = cfg.rl_goal_d
+        self.voc_size = train_dataset.trg_voc_size
+        self.device = torch.device(cfg.device)
+        self.critic_score_threshhold = cfg.rl_critic_score_threshhold
+
+        self.pos_enc_A = PositionalEncoder(cfg.d_model_audio, cfg.dout_p)
+        self.pos_enc_V = PositionalEncoder(cfg.d_model_video, cfg.dout_p)
+        self.pos_enc_C = PositionalEncoder(cfg.d_model_caps, cfg.dout_p)
+        self.critic = SegmentCritic(cfg)
+        self.emb_C = VocabularyEmbedder(train_dataset.trg_voc_size, cfg.d_model_caps)
+        self.emb_C.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
+        self.bm_enc = BMEncoder(self.d_video, self.d_audio, self.d_model, cfg.rl_ff_v, cfg.rl_ff_a, self.dout_p,
+                                self.att_heads, self.att_layers)
+        self.bm_worker_fus = BMFusion(cfg.d_model_audio, cfg.d_model_video, cfg.d_model_caps, cfg.d_model, cfg.rl_ff_c,
+                                      self.dout_p, self.att_heads, self.att_layers)
+        self.bm_manager_fus = BMFusion(cfg.d_model_audio, cfg.d_model_video, cfg.d_model_caps, cfg.d_model, cfg.rl_ff_c,
+                                       self.dout_p, self.att_heads, self.att_layers)
+        self.manager_core = LinearCore(cfg.d_model_caps, cfg.rl_goal_d, cfg.dout_p)
+        self.manager = Manager(self.device, self.d_model_caps, self.d_goal, self.dout_p, self.manager_core)
+        self.worker = Worker(self.voc_size, self.d_model_caps, self.d_goal, self.dout_p, self.d_model)
+
+        self.teach_warmstart()
+        self.warmstarting = True
+        self.teaching_worker = True
+        self.sigmoid_epoch_offset = torch.tensor(-1)
+        self.worker_modules = [self.bm_enc, self.bm_worker_fus, self.worker]
+        self.manager_modules = [self.bm_manager_fus, self.manager]
+
+    # ---- checkpoints (reference :547-553)
+    def save_model(self, checkpoint_dir):
+        torch.save(self.state_dict(), checkpoint_dir + f"/{self.name}.pt")
+
+    def load_model(self, checkpoint_dir):
+        self.load_state_dict(torch.load(checkpoint_dir + f"/{self.name}.pt"))
+
+    # ---- phase switches (reference :555-593)
+    @staticmethod
+    def _set_module_grads(modules, enable):
+        for m in modules:
+            for p in m.parameters():
+                p.requires_grad = enable
+
+    def teach_warmstart(self):
+        self.warmstarting = True
+        self._set_module_grads([self.worker, self.bm_worker_fus, self.manager, self.bm_manager_fus], True)
+
+    def teach_worker(self):
+        self.warmstarting = False
+        self.teaching_worker = True
+        self._set_module_grads(self.worker_modules, True)
+        self._set_module_grads(self.manager_modules, False)
+        self.manager.exploration = False
+
+    def teach_manager(self):
+        self.warmstarting = False
+        self.teaching_worker = False
+        self._set_module_grads(self.worker_modules, False)
+        self._set_module_grads(self.manager_modules, True)
+        self.manager.exploration = True
+
+    def set_inference_mode(self, inference):
+        self.manager.exploration = not inference
+
+    # ---- forward (reference :596-661)
+    def warmstart(self, x, trg, mask):
+        return self.prediction(x, trg, mask)
+
+    def _segment_labels(self, emb):
+        seg = torch.sigmoid(self.critic(emb))
+        return (seg > self.critic_score_threshhold).squeeze().int()
+
+    def _encode(self, x):
+        """x = (V, A) or ((rgb, flow), A): the rgb + flow add is fused into the positional-encoding kernel (K1)."""
+        xv, xa = x
+        V = self.pos_enc_V(xv[0], xv[1]) if isinstance(xv, (tuple, list)) else self.pos_enc_V(xv)
+        return V, self.pos_enc_A(xa)
+
+    def prediction(self, x, trg, mask):
+        emb, C = self.emb_C.embed_posenc(trg, self.pos_enc_C)
+        V, A = self._encode(x)
+        return self.predict_with_features(emb, V, A, mask, C)
+
+    def mixed_prediction(self, x, trgs, mask, mix_factor):
+        y_trg, yhat_trg = trgs
+        emb, C = self.emb_C.embed_posenc(y_trg, self.pos_enc_C, yhat_trg, float(mix_factor))
+        V, A = self._encode(x)
+        return self.predict_with_features(emb, V, A, mask, C)
+
+    def predict_with_features(self, C_emb, V, A, mask, C=None):
+        segment_labels = self._segment_labels(C_emb)
+        if C is None:
+            C = self.pos_enc_C(C_emb)
+        Va, Av = self.bm_enc((V, A), mask)          # Va: video stream (B,Tv,d_vid), Av: audio stream (B,Ta,d_aud)
+        worker_feat = self.bm_worker_fus((C, (Av, Va)), mask)
+        manager_feat = self.bm_manager_fus((C, (Av, Va)), mask)
+        goals = self.manager(manager_feat, segment_labels)
+        pred = self.worker(worker_feat, goals, mask["C_mask"])
+        return pred, worker_feat, manager_feat, goals, segment_labels
+
+    def inference(self, x, trg, mask, *hidden):
+        """3-argument reference form returns the log-probs; the 5-argument call sites of the reference's greedy
+        decoders (epoch_loops/captioning_bmrl_loops.py:72,147) get (log-probs, None, None)."""
+        pred = self.prediction(x, trg, mask)[0]
+        return (pred, None, None) if hidden else pred
+
+    def forward(self, x, trg, mask, factor=1):
+        if type(trg) is tuple:
+            return self.mixed_prediction(x, trg, mask, factor)
+        return self.prediction(x, trg, mask)
+
+
+def agent_state_shapes(cfg, voc_size, with_critic=True):
+    """name -> shape of the agent's state dict without building tensors (meta device)."""
+    from types import SimpleNamespace
+    ds = SimpleNamespace(trg_voc_size=voc_size, train_vocab=SimpleNamespace(vectors=None))
+    saved = getattr(cfg, "rl_critic_path", None)
+    cfg.rl_critic_path = None
+    try:
+        with torch.device("meta"):
+            m = BMHrlAgent(cfg, ds)
+    finally:
+        cfg.rl_critic_path = saved
+    return {k: tuple(v.shape) for k, v in m.state_dict().items() if with_critic or not k.startswith("critic.")}

@@ -1,0 +1,50 @@
+"""Padding / causal masks -- same functions and semantics as the reference's model/masking.py:3-55.
+Plain comparisons on the tensors' own device (they feed the attention kernels as byte masks)."""
+import torch
+
+
+def subsequent_mask(size):
+    """(1, size, size) lower-triangular byte mask.  reference model/masking.py:3-11"""
+    return torch.tril(torch.ones(1, size, size), 0).byte()
+
+
+def c_mask(trg, pad_idx):
+    """key-padding & causal mask of a caption batch, (B, L, L).  reference :13-15"""
+    pad = (trg != pad_idx).unsqueeze(-2)
+    return pad & subsequent_mask(trg.size(-1)).type_as(pad).to(trg.device)
+
+
+def mask(src, trg, pad_idx, data_pad=0):
+    """src (B, S) first feature column -> (B, 1, S); optional caption mask.  reference :18-25"""
+    src_mask = (src != data_pad).unsqueeze(1)
+    if trg is None:
+        return src_mask
+    return src_mask, c_mask(trg, pad_idx)
+
+
+def make_masks(feature_stacks, captions, modality, pad_idx):
+    """reference :28-55.  V_mask comes from rgb[:, :, 0] (before flow is added), A_mask from audio[:, :, 0]."""
+    masks = {}
+    if modality == 'video':
+        if captions is None:
+            masks['V_mask'] = mask(feature_stacks['rgb'][:, :, 0], None, pad_idx)
+        else:
+            masks['V_mask'], masks['C_mask'] = mask(feature_stacks['rgb'][:, :, 0], captions, pad_idx)
+    elif modality == 'audio':
+        assert len(feature_stacks['audio'].shape) == 3
+        if captions is None:
+            masks['A_mask'] = mask(feature_stacks['audio'][:, :, 0], None, pad_idx)
+        else:
+            masks['A_mask'], masks['C_mask'] = mask(feature_stacks['audio'][:, :, 0], captions, pad_idx)
+    elif modality in ('audio_video', 'subs_audio_video'):
+        assert len(feature_stacks['audio'].shape) == 3
+        if captions is None:
+            masks['V_mask'] = mask(feature_stacks['rgb'][:, :, 0], None, pad_idx)
+        else:
+            masks['V_mask'], masks['C_mask'] = mask(feature_stacks['rgb'][:, :, 0], captions, pad_idx)
+        masks['A_mask'] = mask(feature_stacks['audio'][:, :, 0], None, pad_idx)
+        if modality == 'subs_audio_video':
+            masks['S_mask'] = mask(feature_stacks['subs'], None, pad_idx)
+    else:
+        raise ValueError(f'unknown modality {modality}')
+    return masks

@@ -1,0 +1,44 @@
+"""MultiheadedAttention with the reference's constructor, attributes and state-dict keys
+(model/multihead_attention.py:34-92); forward runs the fused HIP path of bmhrl_amd.functional.MHAFn."""
+import torch.nn as nn
+
+from ..functional import MHAFn
+
+
+class MultiheadedAttention(nn.Module):
+
+    def __init__(self, d_model_Q, d_model_K, d_model_V, H, dout_p=0.0, d_model=None):
+        super().__init__()
+        self.d_model_Q, self.d_model_K, self.d_model_V = d_model_Q, d_model_K, d_model_V
+        self.H = H
+        self.d_model = d_model if d_model is not None else d_model_Q
+        self.dout_p = dout_p
+        self.d_k = self.d_model // H
+        assert self.d_model % H == 0
+        self.linear_Q2d = nn.Linear(d_model_Q, self.d_model)
+        self.linear_K2d = nn.Linear(d_model_K, self.d_model)
+        self.linear_V2d = nn.Linear(d_model_V, self.d_model)
+        self.linear_d2Q = nn.Linear(self.d_model, d_model_Q)
+        self.dropout = nn.Dropout(dout_p)
+
+    def _params(self):
+        return (self.linear_Q2d.weight, self.linear_Q2d.bias, self.linear_K2d.weight, self.linear_K2d.bias,
+                self.linear_V2d.weight, self.linear_V2d.bias, self.linear_d2Q.weight, self.linear_d2Q.bias)
+
+    def fused(self, x, kv, mask, norm=None, residual=False, res_dropout=None):
+        """[x +] drop(MHA(LN?(x), kv, kv)).  kv=None -> self attention on the normalised x.
+        The reference applies dout_p twice (attention output, residual branch); both use this module's rate
+        unless the residual connection's own rate is given."""
+        p = self.dout_p if self.training else 0.0
+        ln_w = norm.weight if norm is not None else None
+        ln_b = norm.bias if norm is not None else None
+        return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual)
+
+    def forward(self, Q, K, V, mask, causal=False):
+        """Reference signature: Q (B,Sq,Dq), K/V (B,Sk,Dk), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).
+        K and V must be the same tensor (they are at every call site of the hot path)."""
+        if causal:
+            raise NotImplementedError("causal=True is only used by the DETR decoder (out of scope, SURVEY.md section 2 #5)")
+        if K is not V:
+            raise NotImplementedError("the hot path always passes K is V")
+        return self.fused(Q, None if K is Q else K, mask)

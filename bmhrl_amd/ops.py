@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-EPI_LINEAR, EPI_PROB, EPI_DSCORE = 0, 1, 2
+EPI_LINEAR, EPI_PROB, EPI_DSCORE, EPI_RELU_BWD = 0, 1, 2, 3
 
 
 def pad8(n: int) -> int:
@@ -41,7 +41,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          C_bf16: Optional[torch.Tensor] = None, ldcb=0, cb_strides=(0, 0), cb_off=0,
          epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
-         aux=None, ldaux=0, aux_strides=(0, 0), dropout_p=0.0, seed=0) -> None:
+         aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0)) -> None:
     """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
     _need_cuda(A, B, C_f32, C_bf16)
     d = _lib.GemmDesc()
@@ -56,26 +56,27 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.residual = _p(residual); d.ldr = ldr; d.r_sb1, d.r_sb2 = r_strides
     d.mask = _p(mask); d.mask_sb1 = mask_sb1; d.mask_sm = mask_sm
     d.rowvec = _p(rowvec); d.rowvec2 = _p(rowvec2); d.rv_sb1, d.rv_sb2 = rv_strides
-    d.aux = _p(aux); d.ldaux = ldaux; d.aux_sb1, d.aux_sb2 = aux_strides
-    d.dropout_p = dropout_p; d.seed = seed
+    d.aux = None if aux is None else aux.data_ptr() + 2 * aux_off; d.ldaux = ldaux; d.aux_sb1, d.aux_sb2 = aux_strides
+    d.dropout_p = dropout_p; d.seed = seed; d.seed_dev = _p(seed_dev)
+    d.drop_sb1, d.drop_sb2, d.drop_sm = drop_strides
     _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
 
 
 def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, ldo,
-                  q_off=0, k_off=0, v_off=0, dropout_p=0.0, seed=0):
+                  q_off=0, k_off=0, v_off=0, dropout_p=0.0, seed=0, seed_dev=None):
     _need_cuda(Q, K, V, O)
     _lib.check(_lib.load().bmhrl_attention_fwd(Q.data_ptr() + 2 * q_off, ldq, K.data_ptr() + 2 * k_off, ldk,
                                                V.data_ptr() + 2 * v_off, ldv, O.data_ptr(), ldo, row_max.data_ptr(),
                                                row_sum.data_ptr(), _p(mask), mask_sb, mask_sq, B, H, Sq, Sk, dk, scale,
-                                               dropout_p, seed, stream()), "bmhrl_attention_fwd")
+                                               dropout_p, seed, _p(seed_dev), stream()), "bmhrl_attention_fwd")
 
 
 def softmax_rows(S, lds, P, ldp, rows, cols):
     _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr(), ldp, rows, cols, stream()), "bmhrl_softmax_rows")
 
 
-def attn_delta(dO, lddo, O, ldo, delta, B, H, Sq, dk):
-    _lib.check(_lib.load().bmhrl_attn_delta(dO.data_ptr(), lddo, O.data_ptr(), ldo, delta.data_ptr(), B, H, Sq, dk, stream()),
+def attn_delta(dO, lddo, O, ldo, delta, B, H, Sq, dk, scale=1.0):
+    _lib.check(_lib.load().bmhrl_attn_delta(dO.data_ptr(), lddo, O.data_ptr(), ldo, delta.data_ptr(), scale, B, H, Sq, dk, stream()),
                "bmhrl_attn_delta")
 
 
@@ -85,22 +86,22 @@ def layernorm_fwd(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows, D):
                                                _p(mean), _p(rstd), rows, D, stream()), "bmhrl_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, accumulate_dx, dgamma, dbeta, rows, D):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D):
     _lib.check(_lib.load().bmhrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                               dx.data_ptr(), int(accumulate_dx), _p(dgamma), _p(dbeta), rows, D, stream()),
+                                               dx.data_ptr(), _p(dx_add), _p(dgamma), _p(dbeta), rows, D, stream()),
                "bmhrl_layernorm_bwd")
 
 
-def add_posenc(a, b, pe, out, out_bf16, ldob, B, S, D, dropout_p=0.0, seed=0):
+def add_posenc(a, b, pe, out, out_bf16, ldob, B, S, D, dropout_p=0.0, seed=0, seed_dev=None):
     _need_cuda(a)
     _lib.check(_lib.load().bmhrl_add_posenc(a.data_ptr(), _p(b), pe.data_ptr(), out.data_ptr(), _p(out_bf16), ldob, B, S, D,
-                                            dropout_p, seed, stream()), "bmhrl_add_posenc")
+                                            dropout_p, seed, _p(seed_dev), stream()), "bmhrl_add_posenc")
 
 
-def embed_posenc(tok, tok2, mix, table, pe, emb_out, out, B, L, D, scale, dropout_p=0.0, seed=0):
+def embed_posenc(tok, tok2, mix, table, pe, emb_out, out, B, L, D, scale, dropout_p=0.0, seed=0, seed_dev=None):
     _need_cuda(tok, table)
     _lib.check(_lib.load().bmhrl_embed_posenc(tok.data_ptr(), _p(tok2), mix, table.data_ptr(), pe.data_ptr(), _p(emb_out),
-                                              out.data_ptr(), B, L, D, scale, dropout_p, seed, stream()), "bmhrl_embed_posenc")
+                                              out.data_ptr(), B, L, D, scale, dropout_p, seed, _p(seed_dev), stream()), "bmhrl_embed_posenc")
 
 
 def embed_bwd(tok, tok2, mix, dC, dtable, B, L, D, scale):
@@ -108,10 +109,10 @@ def embed_bwd(tok, tok2, mix, dC, dtable, B, L, D, scale):
                                            stream()), "bmhrl_embed_bwd")
 
 
-def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_off=0):
+def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_off=0, seed_dev=None):
     _need_cuda(x, y)
     _lib.check(_lib.load().bmhrl_cast_bf16(x.data_ptr(), ldx, y.data_ptr() + 2 * y_off, ldy, rows, cols, scale, dropout_p,
-                                           seed, stream()), "bmhrl_cast_bf16")
+                                           seed, _p(seed_dev), stream()), "bmhrl_cast_bf16")
 
 
 def colsum_bf16(dY, ld, db, accumulate, rows, cols, dy_off=0, db_off=0):
@@ -154,10 +155,15 @@ def smooth_kl_fwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, z
 
 
 def smooth_kl_bwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, g_bf16, ldg,
-                  g_f32, rows, V):
+                  g_f32, rows, V, wrt_logits=True):
     _lib.check(_lib.load().bmhrl_smooth_kl_bwd(logp.data_ptr(), ld, trg.data_ptr(), _p(biased_trg), _p(score), _p(n_row),
-                                               smoothing, pad_idx, zero_pad_rows, loss_scale.data_ptr(), _p(g_bf16), ldg,
+                                               smoothing, pad_idx, zero_pad_rows, loss_scale.data_ptr(), int(wrt_logits), _p(g_bf16), ldg,
                                                _p(g_f32), rows, V, stream()), "bmhrl_smooth_kl_bwd")
+
+
+def log_softmax_bwd(dlogp, logp, ld, g_bf16, ldg, rows, V):
+    _lib.check(_lib.load().bmhrl_log_softmax_bwd(dlogp.data_ptr(), logp.data_ptr(), ld, g_bf16.data_ptr(), ldg, rows, V, stream()),
+               "bmhrl_log_softmax_bwd")
 
 
 def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed):
@@ -171,6 +177,6 @@ def reinforce_fwd(logp, ld, action, value, critic_value, row_policy, row_value, 
                                                stream()), "bmhrl_reinforce_fwd")
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_dev=None):
     _lib.check(_lib.load().bmhrl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, lr,
-                                           beta1, beta2, eps, weight_decay, step, grad_scale, stream()), "bmhrl_adam_step")
+                                           beta1, beta2, eps, weight_decay, step, _p(step_dev), grad_scale, stream()), "bmhrl_adam_step")

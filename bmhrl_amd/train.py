@@ -1,0 +1,213 @@
+"""The per-batch training step of the hot path (epoch_loops/captioning_bmrl_loops.py:1148-1160 warmstart,
+:837-877 worker RL step) over the HIP-backed agent, with
+
+  * one flat fp32 bucket for the trainable parameters and one for their gradients (frozen / never-reached
+    parameters excluded: critic, BMFusionLayer.feed_forward, manager_core -- SURVEY.md section 7),
+  * RCCL all-reduce of the flat gradient bucket for data parallel runs (one process per GPU),
+  * one fused Adam launch per bucket (torch.optim.Adam semantics, the reference's default betas / eps),
+  * optional whole-step HIP graph capture (static shapes; dropout seeds advance through a device word).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops, synthetic as syn
+from .functional import SEEDS, SHADOWS
+from .loss.biased_kl import BiasedKL
+from .loss.label_smoothing import LabelSmoothing
+from .model.bm_hrl_agent import BMHrlAgent, BMWorkerValueFunction
+from .model.masking import make_masks
+
+
+class FlatAdam:
+    """Adam over parameters re-homed into one flat fp32 buffer (views keep the nn.Parameter objects and the
+    state-dict layout intact).  `params` that never receive a gradient keep a zero slot."""
+
+    def __init__(self, params: List[torch.nn.Parameter], lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        self.offsets = []
+        n = 0
+        for s in self.sizes:
+            self.offsets.append(n)
+            n += (s + 3) & ~3          # keep every slice 16-byte aligned
+        self.n = n
+        self.flat = torch.zeros(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        for p, o, s in zip(self.params, self.offsets, self.sizes):
+            self.flat[o:o + s].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + s].view(p.shape)
+        self.grad_views = [self.grad[o:o + s].view(p.shape) for p, o, s in zip(self.params, self.offsets, self.sizes)]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # advanced on the device (graph-safe)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """copy the autograd gradients into the flat bucket (one multi-tensor copy); missing ones stay zero"""
+        dst, src, missing = [], [], []
+        for p, gv in zip(self.params, self.grad_views):
+            if p.grad is None:
+                missing.append(gv)
+            else:
+                dst.append(gv)
+                src.append(p.grad)
+        if missing:
+            torch._foreach_zero_(missing)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def all_reduce(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            return 1.0 / dist.get_world_size(group)
+        return 1.0
+
+    def step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        b1, b2 = self.betas
+        if self.flat.is_cuda:
+            self.step_dev.add_(1)
+            ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, self.lr, b1, b2, self.eps,
+                          self.weight_decay, self.step_count, grad_scale, step_dev=self.step_dev)
+        else:  # host-side reference used by the gloo tests of the data-parallel plumbing (no model arithmetic)
+            g = self.grad * grad_scale
+            if self.weight_decay:
+                g = g + self.weight_decay * self.flat
+            self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1 = 1 - b1 ** self.step_count
+            bc2 = 1 - b2 ** self.step_count
+            self.flat.addcdiv_(self.exp_avg, (self.exp_avg_sq.sqrt() / bc2 ** 0.5).add_(self.eps), value=-self.lr / bc1)
+        SHADOWS.invalidate()   # bf16 weight shadows are stale now
+
+
+def trainable_bucket(agent: BMHrlAgent) -> List[torch.nn.Parameter]:
+    """Parameters the captioning loss can reach (the reference's optimiser holds all of them, but these are the only
+    ones that ever receive a gradient): excludes the frozen critic, the never-applied fusion feed_forward and the
+    unused manager_core (model/bm_hrl_agent.py:66,198-199,438)."""
+    out = []
+    for name, p in agent.named_parameters():
+        if name.startswith("critic.") or ".feed_forward.fc" in name and "_fus." in name or name.startswith("manager_core.") \
+                or name.startswith("manager.core."):
+            continue
+        if p.requires_grad:
+            out.append(p)
+    return out
+
+
+class CaptionTrainer:
+    """Owns agent + optimiser state for the captioning half of the reference's step on one GPU (one rank)."""
+
+    def __init__(self, cfg, voc_size: int, device, lr: float = 1e-4, weight_decay: float = 0.0, seed: int = 0,
+                 critic_state: Optional[Dict[str, torch.Tensor]] = None, pad_idx: int = 1, smoothing: float = 0.7):
+        cfg.device = str(device)
+        ds = SimpleNamespace(trg_voc_size=voc_size, train_vocab=SimpleNamespace(vectors=None))
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.agent = BMHrlAgent(cfg, ds)
+        shapes = {k: tuple(v.shape) for k, v in self.agent.state_dict().items()}
+        sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=seed, clone_layers=True)
+        crit = critic_state if critic_state is not None else syn.synthetic_critic_state(cfg.d_model_caps, seed=1)
+        sd.update({"critic." + k: v for k, v in crit.items()})
+        self.agent.load_state_dict(sd)
+        self.agent.to(self.device)
+        self.agent.set_inference_mode(True)     # manager.exploration off (worker / warmstart phases)
+        self.pad_idx = pad_idx
+        self.criterion = LabelSmoothing(smoothing, pad_idx)
+        self.rl_criterion = BiasedKL(smoothing, pad_idx)
+        self.opt = FlatAdam(trainable_bucket(self.agent), lr=lr, weight_decay=weight_decay)
+        self.modality = "audio_video"
+        self.graph = None
+        self.static = None
+        SEEDS.dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    # ------------------------------------------------------------------ one step, eager
+    def _forward_loss(self, fs, trg_in, trg_y, rl=None):
+        masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
+        pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
+        loss_mask = trg_y != self.pad_idx
+        n_tokens = loss_mask.sum()
+        if rl is None:
+            loss = torch.sum(self.criterion(pred, trg_y)) / n_tokens
+        else:
+            sampled, score = rl
+            n_row = loss_mask.sum(-1, keepdim=True).expand_as(trg_y).float()
+            rows, _ = self.rl_criterion.biased_kl_from_score(pred, trg_y, sampled, score, n_row)
+            loss = torch.sum(rows) / (n_tokens * (4.0 / 20.0))
+        return loss, pred
+
+    def step(self, fs, captions, rl=None):
+        """zero_grad -> forward -> loss -> backward -> (all-reduce) -> Adam.  Returns the loss (device scalar)."""
+        trg_in, trg_y = captions[:, :-1].contiguous(), captions[:, 1:].contiguous()
+        self.opt.zero_grad()
+        SEEDS.dev.add_(1)
+        loss, _ = self._forward_loss(fs, trg_in, trg_y, rl)
+        loss.backward()
+        self.opt.gather_grads()
+        scale = self.opt.all_reduce()
+        self.opt.step(scale)
+        return loss.detach()
+
+    # ------------------------------------------------------------------ whole-step HIP graph
+    def capture(self, fs, captions, warmup: int = 3):
+        """Capture step() for static shapes; afterwards replay(fs, captions) copies the inputs into the captured
+        buffers and launches the graph.  The all-reduce stays outside the graph (between two captured halves) when
+        a process group is active, so RCCL sees ordinary stream launches."""
+        self.static = {k: v.clone() for k, v in fs.items()}
+        self.static["captions"] = captions.clone()
+        self.static_loss = torch.zeros((), device=self.device)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._graph_body_a()
+                self._graph_body_b(1.0)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self._graph_body_a()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            self._graph_body_b(self._world_scale())
+        self.graph = True
+
+    @staticmethod
+    def _world_scale():
+        return 1.0 / dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1.0
+
+    def _graph_body_a(self):
+        st = self.static
+        cap = st["captions"]
+        trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
+        self.opt.zero_grad()
+        SEEDS.dev.add_(1)
+        SHADOWS.invalidate()
+        loss, _ = self._forward_loss(st, trg_in, trg_y)
+        loss.backward()
+        self.opt.gather_grads()
+        self.static_loss.copy_(loss.detach())
+
+    def _graph_body_b(self, scale):
+        self.opt.step(scale)
+
+    def replay(self, fs=None, captions=None):
+        if fs is not None:
+            for k in ("rgb", "flow", "audio"):
+                self.static[k].copy_(fs[k])
+            self.static["captions"].copy_(captions)
+        self.graph_a.replay()
+        self.opt.all_reduce()
+        self.graph_b.replay()
+        return self.static_loss

@@ -36,7 +36,8 @@ typedef void* bmhrl_stream_t; /* hipStream_t */
 enum {
   BMHRL_EPI_LINEAR = 0, /* v = alpha*acc (+bias[n]) ; mask==0 -> -1e9 ; relu ; dropout ; (+residual[m][n]) */
   BMHRL_EPI_PROB = 1,   /* p = exp(masked(alpha*acc) - rowvec[m]) / rowvec2[m]        (recompute softmax P) */
-  BMHRL_EPI_DSCORE = 2  /* ds = aux[m][n] * (acc - rowvec[m]) * alpha               (softmax backward)     */
+  BMHRL_EPI_DSCORE = 2, /* ds = aux[m][n] * (acc - rowvec[m]) * alpha               (softmax backward)     */
+  BMHRL_EPI_RELU_BWD = 3 /* dz = aux[m][n] > 0 ? alpha*acc : 0     (ReLU + inverted-dropout backward of the FFN) */
 };
 
 typedef struct bmhrl_gemm_desc {
@@ -55,7 +56,9 @@ typedef struct bmhrl_gemm_desc {
   const uint8_t* mask; int64_t mask_sb1, mask_sm; /* byte mask[b1][m*mask_sm + n], mask_sm may be 0 */
   const float* rowvec; const float* rowvec2; int64_t rv_sb1, rv_sb2; /* per-row fp32 vectors: (row max, row sum) or delta */
   const void* aux; int64_t ldaux, aux_sb1, aux_sb2; /* bf16 [M][N] (P for DSCORE) */
-  float dropout_p; uint64_t seed;                 /* inverted dropout on v, element id = ((batch*M + m)*N + n) */
+  float dropout_p; uint64_t seed;                 /* inverted dropout on v; element id = b1*drop_sb1 + b2*drop_sb2 + m*drop_sm + n */
+  int64_t drop_sb1, drop_sb2, drop_sm;            /* (all 0 -> id = (batch*M + m)*N + n) */
+  const uint64_t* seed_dev;                       /* optional device word added to seed (changes under graph replay) */
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
@@ -75,41 +78,42 @@ int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, 
                         void* O, int64_t ldo, float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
                         int64_t mask_sq,
                         int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t DK, float scale,
-                        float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
 
 /* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
  * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */
 int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
                        bmhrl_stream_t stream);
 
-/* delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (softmax backward row term) */
-int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta,
+/* delta[b,h,q] = scale * sum_d dO[b,q,h,d] * O[b,q,h,d]   (softmax backward row term) */
+int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale,
                      int32_t B, int32_t H, int32_t Sq, int32_t DK, bmhrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (eps 1e-5, affine) -- nn.LayerNorm inside ResidualConnection, model/blocks.py:132,138,
  * and normCA/normCV, model/bm_hrl_agent.py:68-69,107-108.
  *   fwd: x fp32 (rows, D) -> y bf16 (rows, ldy) and/or y32 fp32 (rows, D); saves mean, rstd.
- *   bwd: dx (+)= LN'(dy) ; dgamma/dbeta accumulated with fp32 atomics into zeroed buffers.
+ *   bwd: dx = [dx_add +] LN'(dy) ; dgamma/dbeta accumulated with fp32 atomics into zeroed buffers.
  * ------------------------------------------------------------------------------------------- */
 int bmhrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, int64_t ldy,
                         float* y_f32, float* mean, float* rstd, int64_t rows, int32_t D, bmhrl_stream_t stream);
 int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                        float* dx, int32_t accumulate_dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
-                        bmhrl_stream_t stream);
+                        float* dx, const float* dx_add /* optional: dx = dx_add + LN'(dy) */, float* dgamma,
+                        float* dbeta, int64_t rows, int32_t D, bmhrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Feature add + positional encoding (K1): out = a (+ b) + PE[s]  (epoch_loops/captioning_bmrl_loops.py:498,
  * model/blocks.py:105-112).  pe is the precomputed fp32 table (S_max, D).  Optional bf16 copy and dropout.
  * ------------------------------------------------------------------------------------------- */
 int bmhrl_add_posenc(const float* a, const float* b, const float* pe, float* out, void* out_bf16, int64_t ldob,
-                     int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+                     int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                     bmhrl_stream_t stream);
 
 /* Embedding * sqrt(D) (+ second embedding mix) + PE : model/blocks.py:44-48, model/bm_hrl_agent.py:611-625,642.
  * emb_out (B,L,D) fp32 = un-positional-encoded embeddings (critic input); out = emb_out + PE. */
 int bmhrl_embed_posenc(const int64_t* tok, const int64_t* tok2, float mix, const float* table, const float* pe,
                        float* emb_out, float* out, int32_t B, int32_t L, int32_t D, float scale,
-                       float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
 /* dTable[tok] += scale * (1-mix) * dC ; dTable[tok2] += scale * mix * dC  (fp32 atomics) */
 int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const float* dC, float* dtable,
                     int32_t B, int32_t L, int32_t D, float scale, bmhrl_stream_t stream);
@@ -117,7 +121,7 @@ int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const fl
 /* fp32 -> bf16 cast of a (rows, cols) matrix into a padded-leading-dimension buffer, with optional scale
  * and inverted dropout (regenerates the forward mask from seed: element id = row*cols + col). */
 int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
-                    float dropout_p, uint64_t seed, bmhrl_stream_t stream);
+                    float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
 
 /* db[n] (+)= sum_m dY[m][n]  (bias gradient of nn.Linear), dY bf16 */
 int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t accumulate, int64_t rows, int32_t cols,
@@ -145,8 +149,10 @@ int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, float* dx, int
  *                       BiasedKL (loss/biased_kl.py:22-53) over the unreduced (rows, V) divergence, never
  *                       materialising the target distribution; amp = clamp(score*p(a)*n_row, 0, 1) is computed
  *                       here (epoch_loops/captioning_bmrl_loops.py:285,321-322,409-416).
- *  bmhrl_smooth_kl_bwd: d(loss_scale * sum)/d logits -> bf16 (rows, ldg) incl. the path through amp.
- *  zero_pad_rows: the reference's `idx.sum() > 0` guard decided on the host side (1 = zero pad rows).
+ *  bmhrl_smooth_kl_bwd: d(loss_scale * sum)/d logits (wrt_logits = 1, log-softmax folded in) or /d log-probs
+ *                       (wrt_logits = 0) -> bf16 (rows, ldg) and/or fp32 (rows, V), incl. the path through amp.
+ *  bmhrl_log_softmax_bwd: dlogits = dlogp - exp(logp) * rowsum(dlogp) -> bf16 (rows, ldg)
+ *  zero_pad_rows: the reference's `idx.sum() > 0` guard: 1/0 forces it, -1 lets the kernel evaluate it on the device.
  * ------------------------------------------------------------------------------------------- */
 int bmhrl_log_softmax(float* logits, int64_t ld, int64_t rows, int32_t V, bmhrl_stream_t stream);
 int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
@@ -155,8 +161,10 @@ int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t* trg, const
                         bmhrl_stream_t stream);
 int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
                         const float* score, const float* n_row, float smoothing, int32_t pad_idx,
-                        int32_t zero_pad_rows, const float* loss_scale /* device scalar */, void* dlogits_bf16,
-                        int64_t ldg, float* dlogits_f32, int64_t rows, int32_t V, bmhrl_stream_t stream);
+                        int32_t zero_pad_rows, const float* loss_scale /* device scalar */, int32_t wrt_logits,
+                        void* grad_bf16, int64_t ldg, float* grad_f32, int64_t rows, int32_t V, bmhrl_stream_t stream);
+int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, void* dlogits_bf16, int64_t ldg,
+                          int64_t rows, int32_t V, bmhrl_stream_t stream);
 /* a ~ Categorical(exp(logp)) by inverse CDF with one uniform per row (counter RNG: seed, row);
  * greedy != 0 -> argmax.  epoch_loops/captioning_bmrl_loops.py:283-284 */
 int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
@@ -172,8 +180,9 @@ int bmhrl_reinforce_fwd(const float* logp, int64_t ld, const int64_t* action, co
  * the gradient first (1/world for data parallel averaging).
  * ------------------------------------------------------------------------------------------- */
 int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
-                    bmhrl_stream_t stream);
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                    const int32_t* step_dev /* optional: step count read on the device (graph replay) */,
+                    float grad_scale, bmhrl_stream_t stream);
 
 /* Library self-description: returns the gfx target the kernels were built for ("gfx950"). */
 const char* bmhrl_hip_arch(void);

@@ -1,0 +1,226 @@
+"""Block-level forward/backward parity (GPU): each fused autograd block of bmhrl_amd.functional against the same
+block written with plain torch fp32 ops and autograd on bf16-rounded weights.  Medium sizes, so bf16 rounding noise
+averages out: tolerance 1e-2 on every gradient (max|a-b| / max|ref|), 5e-3 on outputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b, floor=1e-6):
+    a, b = a.detach().double(), b.detach().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
+
+
+def bfr(t):
+    """round to bf16 and back: the value the kernels see"""
+    return t.to(torch.bfloat16).float()
+
+
+def leaf(*shape, scale=1.0, g=None, dev=None):
+    return (torch.randn(*shape, generator=g) * scale).to(dev).requires_grad_(True)
+
+
+def ref_mha(x, kv, ln, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, residual):
+    xn = F.layer_norm(x, (x.shape[-1],), ln[0], ln[1], 1e-5) if ln is not None else x
+    src = xn if kv is None else kv
+    B, Sq, _ = x.shape
+    Q = F.linear(xn, bfr(wq), bq)
+    K = F.linear(src, bfr(wk), bk)
+    V = F.linear(src, bfr(wv), bv)
+    D = Q.shape[-1]
+    dk = D // H
+    sp = lambda t: t.view(B, -1, H, dk).transpose(1, 2)
+    s = sp(Q) @ sp(K).transpose(-1, -2) / math.sqrt(dk)
+    s = s.masked_fill(~mask.bool().unsqueeze(1), -1e9)
+    o = (torch.softmax(s, -1) @ sp(V)).transpose(1, 2).reshape(B, Sq, D)
+    y = F.linear(o, bfr(wo), bo)
+    return x + y if residual else y
+
+
+@pytest.mark.parametrize("case", ["self_flash", "cross_flash", "self_mat", "cross_mat", "goal"])
+def test_mha_block(dev, case):
+    from bmhrl_amd.functional import MHAFn
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    B = 2
+    if case == "self_flash":
+        dq = dkv = 128; D, H, Sq, Sk = 1024, 4, 200, 200; cross = False; ln = True; res = True
+    elif case == "cross_flash":
+        dq, dkv, D, H, Sq, Sk = 1024, 128, 1024, 4, 136, 300; cross = True; ln = True; res = True
+    elif case == "self_mat":
+        dq = dkv = 300; D, H, Sq, Sk = 1024, 4, 30, 30; cross = False; ln = True; res = True
+    elif case == "cross_mat":
+        dq, dkv, D, H, Sq, Sk = 300, 128, 1024, 4, 30, 203; cross = True; ln = True; res = True
+    else:  # worker goal attention: H=2, d_k=512, no LN, no residual
+        dq, dkv, D, H, Sq, Sk = 64, 300, 1024, 2, 30, 30; cross = True; ln = False; res = False
+    x = leaf(B, Sq, dq, g=g, dev=dev)
+    kv = leaf(B, Sk, dkv, g=g, dev=dev) if cross else None
+    lnw = (1 + 0.1 * torch.randn(dq, generator=g)).to(dev).requires_grad_(True) if ln else None
+    lnb = (0.1 * torch.randn(dq, generator=g)).to(dev).requires_grad_(True) if ln else None
+    wq = leaf(D, dq, scale=1 / math.sqrt(dq), g=g, dev=dev); bq = leaf(D, scale=0.1, g=g, dev=dev)
+    wk = leaf(D, dkv, scale=1 / math.sqrt(dkv), g=g, dev=dev); bk = leaf(D, scale=0.1, g=g, dev=dev)
+    wv = leaf(D, dkv, scale=1 / math.sqrt(dkv), g=g, dev=dev); bv = leaf(D, scale=0.1, g=g, dev=dev)
+    wo = leaf(dq, D, scale=1 / math.sqrt(D), g=g, dev=dev); bo = leaf(dq, scale=0.1, g=g, dev=dev)
+    if case in ("self_mat", "goal"):
+        mask = torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)).repeat(B, 1, 1)
+        mask[1, :, 22:] = False
+    else:
+        mask = torch.ones(B, 1, Sk, dtype=torch.bool)
+        mask[0, 0, Sk - Sk // 4:] = False
+    mask = mask.to(dev)
+    params = [x, kv, lnw, lnb, wq, bq, wk, bk, wv, bv, wo, bo]
+    y = MHAFn.apply(*params, mask, H, 0.0, res)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(dy)
+    got = [p.grad.clone() if p is not None else None for p in params]
+    for p in params:
+        if p is not None:
+            p.grad = None
+    yr = ref_mha(x, kv, (lnw, lnb) if ln else None, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, res)
+    yr.backward(dy)
+    assert rel(y, yr) < 5e-3
+    names = ["x", "kv", "lnw", "lnb", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo"]
+    for n, p, gg in zip(names, params, got):
+        if p is None:
+            continue
+        # d/d(key bias) is analytically 0 (softmax shift invariance): both sides hold rounding noise only, so it
+        # is compared on the scale of the query-bias gradient
+        floor = float(bq.grad.abs().max()) if n == "bk" else 1e-6
+        assert rel(gg, p.grad, floor) < (3e-2 if n == "bk" else 1e-2), (case, n, rel(gg, p.grad, floor))
+
+
+def test_ffn_block(dev):
+    from bmhrl_amd.functional import FFNFn
+    g = torch.Generator().manual_seed(1)
+    B, S, d, dff = 4, 160, 128, 512
+    x = leaf(B, S, d, g=g, dev=dev)
+    lnw = (1 + 0.1 * torch.randn(d, generator=g)).to(dev).requires_grad_(True)
+    lnb = (0.1 * torch.randn(d, generator=g)).to(dev).requires_grad_(True)
+    w1 = leaf(dff, d, scale=1 / math.sqrt(d), g=g, dev=dev); b1 = leaf(dff, scale=0.1, g=g, dev=dev)
+    w2 = leaf(d, dff, scale=1 / math.sqrt(dff), g=g, dev=dev); b2 = leaf(d, scale=0.1, g=g, dev=dev)
+    params = [x, lnw, lnb, w1, b1, w2, b2]
+    y = FFNFn.apply(*params, 0.0)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(dy)
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    # the reference rounds where the kernels round (straight-through), otherwise pre-activations within bf16
+    # noise of 0 flip their ReLU mask and the two gradients differ by O(1) on those units
+    st = lambda t: t + (bfr(t) - t).detach()
+    xn = st(F.layer_norm(x, (d,), lnw, lnb, 1e-5))
+    yr = x + F.linear(st(torch.relu(F.linear(xn, bfr(w1), b1))), bfr(w2), b2)
+    yr.backward(dy)
+    assert rel(y, yr) < 5e-3
+    for n, p, gg in zip(["x", "lnw", "lnb", "w1", "b1", "w2", "b2"], params, got):
+        assert rel(gg, p.grad) < 1e-2, (n, rel(gg, p.grad))
+
+
+def test_ffn_block_dropout_is_consistent(dev):
+    """Train-mode dropout: the backward regenerates the forward masks (checked by finite differences in the
+    direction of dy on the same seeds is not possible through fresh seeds, so check the mask algebra instead:
+    d(sum y)/dx with p>0 equals the p=0 gradient wherever nothing was dropped, and outputs keep E[y]."""
+    from bmhrl_amd.functional import FFNFn
+    g = torch.Generator().manual_seed(2)
+    B, S, d, dff = 2, 64, 128, 256
+    x = leaf(B, S, d, g=g, dev=dev)
+    lnw = torch.ones(d, device=dev, requires_grad=True); lnb = torch.zeros(d, device=dev, requires_grad=True)
+    w1 = leaf(dff, d, scale=1 / math.sqrt(d), g=g, dev=dev); b1 = leaf(dff, scale=0.1, g=g, dev=dev)
+    w2 = leaf(d, dff, scale=1 / math.sqrt(dff), g=g, dev=dev); b2 = leaf(d, scale=0.1, g=g, dev=dev)
+    ys = torch.stack([FFNFn.apply(x, lnw, lnb, w1, b1, w2, b2, 0.3).detach() for _ in range(64)])
+    y0 = FFNFn.apply(x, lnw, lnb, w1, b1, w2, b2, 0.0).detach()
+    # residual passes x through untouched; the branch is unbiased under inverted dropout
+    assert rel(ys.mean(0), y0) < 0.15
+    y = FFNFn.apply(x, lnw, lnb, w1, b1, w2, b2, 0.3)
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all() and torch.isfinite(w1.grad).all()
+    # fc2 bias gradient = number of kept output elements / (1-p) per column
+    kept = (y.detach() - x.detach()) != 0
+    assert rel(b2.grad, kept.float().sum((0, 1)) / 0.7) < 1e-2
+
+
+def test_linear_layernorm_gate_workerhead(dev):
+    from bmhrl_amd.functional import GateFn, LayerNormFn, LinearFn, WorkerHeadFn
+    g = torch.Generator().manual_seed(3)
+    B, L, d, dg, V = 4, 30, 300, 64, 1000
+    x = leaf(B, L, d, g=g, dev=dev)
+    w = leaf(dg, d, scale=1 / math.sqrt(d), g=g, dev=dev); b = leaf(dg, scale=0.1, g=g, dev=dev)
+    y = LinearFn.apply(x, w, b, True, 0.0)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(dy)
+    got = [x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    x.grad = w.grad = b.grad = None
+    yr = torch.relu(F.linear(bfr(x), bfr(w), b))
+    yr.backward(dy)
+    assert rel(y, yr) < 5e-3
+    for a, p in zip(got, (x, w, b)):
+        assert rel(a, p.grad) < 1e-2
+    # LayerNorm fp32 + gate
+    ca = leaf(B, L, d, g=g, dev=dev); cv = leaf(B, L, d, g=g, dev=dev)
+    lw = (1 + 0.1 * torch.randn(d, generator=g)).to(dev).requires_grad_(True); lb = leaf(d, scale=0.1, g=g, dev=dev)
+    a = torch.tensor([0.4], device=dev, requires_grad=True)
+    out = GateFn.apply(LayerNormFn.apply(cv, lw, lb), LayerNormFn.apply(ca, lw, lb), a)
+    do = torch.randn(out.shape, generator=g).to(dev)
+    out.backward(do)
+    got = [t.grad.clone() for t in (ca, cv, lw, lb, a)]
+    for t in (ca, cv, lw, lb, a):
+        t.grad = None
+    gt = torch.sigmoid(torch.clamp(a, -2, 2))
+    ref = gt * F.layer_norm(cv, (d,), lw, lb, 1e-5) + (1 - gt) * F.layer_norm(ca, (d,), lw, lb, 1e-5)
+    ref.backward(do)
+    assert rel(out, ref) < 1e-5
+    for aa, t in zip(got, (ca, cv, lw, lb, a)):
+        assert rel(aa, t.grad) < 1e-4
+    # worker head: cat + projection + log-softmax
+    x.grad = None
+    gc = leaf(B, L, dg, g=g, dev=dev)
+    wp = leaf(V, d + dg, scale=1 / math.sqrt(d + dg), g=g, dev=dev); bp = leaf(V, scale=0.1, g=g, dev=dev)
+    lp = WorkerHeadFn.apply(x, gc, wp, bp)
+    dlp = torch.randn(lp.shape, generator=g).to(dev) * 0.1
+    lp.backward(dlp)
+    got = [t.grad.clone() for t in (x, gc, wp, bp)]
+    for t in (x, gc, wp, bp):
+        t.grad = None
+    ref = torch.log_softmax(F.linear(torch.cat([bfr(x), bfr(gc)], -1), bfr(wp), bp), -1)
+    ref.backward(dlp)
+    assert rel(lp, ref) < 1e-4
+    for aa, t in zip(got, (x, gc, wp, bp)):
+        assert rel(aa, t.grad) < 1e-2
+
+
+def test_embed_and_expand_goals_backward(dev):
+    from bmhrl_amd.functional import EmbedFn, ExpandGoalsFn
+    from oracle.bmhrl_oracle import expand_goals, posenc_table
+    g = torch.Generator().manual_seed(4)
+    V, D, B, L = 40, 20, 3, 7
+    table = leaf(V, D, g=g, dev=dev)
+    tok = torch.randint(0, V, (B, L), generator=g).to(dev)
+    pe = posenc_table(64, D).float().to(dev)
+    emb, out = EmbedFn.apply(table, tok, None, 0.0, pe, 0.0)
+    do = torch.randn(out.shape, generator=g).to(dev)
+    out.backward(do)
+    got = table.grad.clone(); table.grad = None
+    ref = F.embedding(tok, table) * math.sqrt(D) + pe[:L]
+    ref.backward(do)
+    assert rel(out, ref) < 1e-6 and rel(got, table.grad) < 1e-5
+    goals = leaf(B, L, 5, g=g, dev=dev)
+    seg = torch.tensor([[0, 1, 0, 0, 1, 0, 0], [0] * 7, [1, 0, 0, 0, 0, 0, 1]], dtype=torch.int32)
+    o = ExpandGoalsFn.apply(goals, seg.to(dev))
+    do = torch.randn(o.shape, generator=g).to(dev)
+    o.backward(do)
+    got = goals.grad.clone(); goals.grad = None
+    gc = goals.detach().cpu().requires_grad_(True)
+    r = expand_goals(gc, seg)
+    r.backward(do.cpu())
+    assert torch.equal(o.detach().cpu(), r.detach()) and rel(got.cpu(), gc.grad) < 1e-6

@@ -227,9 +227,10 @@ def test_layernorm(dev, rows, D):
     ref.backward(dy.double())
     assert rel_err(yf, ref) < 1e-5
     assert rel_err(yb[:, :D].float(), ref) < 1e-2
-    dx = torch.ones(rows, D, device=dev)
+    dx = torch.empty(rows, D, device=dev)
     dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
-    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, True, dg, db, rows, D)
+    ones = torch.ones(rows, D, device=dev)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, ones, dg, db, rows, D)
     assert rel_err(dx - 1, xr.grad) < 2e-5
     assert rel_err(dg, gr.grad) < 2e-5
     assert rel_err(db, br.grad) < 2e-5
@@ -344,6 +345,12 @@ def test_loss_kernels_vs_oracle(dev, golden):
     ops.smooth_kl_bwd(lp, V, t, None, None, None, 0.7, 1, -1, scale, gb, gb.shape[1], gf, rows, V)
     assert rel_err(gf, torch.from_numpy(g["ls_grad_logits"]).reshape(rows, V)) < 1e-5
     assert rel_err(gb[:, :V].float(), gf) < 1e-2
+    # the same gradient in two steps: d/d log-probs, then the log-softmax backward kernel
+    glp = torch.empty(rows, V, device=dev)
+    ops.smooth_kl_bwd(lp, V, t, None, None, None, 0.7, 1, -1, scale, None, 0, glp, rows, V, wrt_logits=False)
+    g2 = ops.bf16_zeros(rows, V, dev)
+    ops.log_softmax_bwd(glp, lp, V, g2, g2.shape[1], rows, V)
+    assert rel_err(g2[:, :V].float(), gf) < 1e-2
     a = sampled.reshape(-1).to(dev)
     mask = (trg != 1)
     n_row = mask.sum(-1, keepdim=True).expand(B, S).reshape(-1).float().to(dev)
