@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
         ("B", ptr), ("ldb", i64), ("b_sb1", i64), ("b_sb2", i64), ("b_trans", i32),
         ("C", ptr), ("ldc", i64), ("c_sb1", i64), ("c_sb2", i64),
         ("Cb", ptr), ("ldcb", i64), ("cb_sb1", i64), ("cb_sb2", i64),
-        ("epilogue", i32), ("alpha", f32), ("relu", i32), ("accumulate", i32),
+        ("epilogue", i32), ("alpha", f32), ("relu", i32), ("accumulate", i32), ("allow_split_k", i32),
         ("bias", ptr),
         ("residual", ptr), ("ldr", i64), ("r_sb1", i64), ("r_sb2", i64),
         ("mask", ptr), ("mask_sb1", i64), ("mask_sm", i64),

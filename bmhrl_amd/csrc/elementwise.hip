@@ -77,13 +77,23 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
       }
     }
   }
+  // block-level reduction of the 4 waves' partial sums, then ONE atomic per column per block (per-row or per-wave
+  // atomics onto the same D addresses serialise: 14x slower, MI355X_MICROARCH 'Global float atomics')
+  __shared__ float red[ROWS_PER_BLOCK][64 * LN_MAXC];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < D) {
-      if (dgamma) atomicAdd(dgamma + c, dg[i]);
-      if (dbeta) atomicAdd(dbeta + c, db[i]);
+  for (int pass = 0; pass < 2; ++pass) {
+    float* out = pass == 0 ? dgamma : dbeta;
+    if (!out) continue;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) red[w][c] = pass == 0 ? dg[i] : db[i];
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x)
+      atomicAdd(out + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
   }
 }
 
@@ -285,8 +295,8 @@ extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float*
                                    const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
                                    int64_t rows, int32_t D, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 64 * LN_MAXC);
-  // enough waves to fill the chip (2048+), at most 32 rows per wave so the atomics stay ~rows/32 per column
-  int rpw = (int)((rows + 4095) / 4096);
+  // ~512 blocks (2048 waves): fills the chip and keeps the dgamma/dbeta atomics at ~512 per column
+  int rpw = (int)((rows + 2047) / 2048);
   if (rpw < 1) rpw = 1;
   if (rpw > 32) rpw = 32;
   const long waves = (rows + rpw - 1) / rpw;

@@ -28,7 +28,7 @@ struct GemmArgs {
   const float* rowvec; const float* rowvec2; long rv_sb1, rv_sb2;
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
-  int tiles_m;
+  int tiles_m, splits, k_per_split, vec_ok;
 };
 
 constexpr int BK = 64;
@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
   const bf16_t* __restrict__ Ag = p.A + b1 * p.a_sb1 + b2 * p.a_sb2;
   const bf16_t* __restrict__ Bg = p.B + b1 * p.b_sb1 + b2 * p.b_sb2;
-  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7, K8 = (p.K + 7) & ~7;
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  // split-K: this block reduces k in [k_begin, k_end)
+  const int k_begin = blockIdx.y * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int K8 = (k_end == p.K) ? ((p.K + 7) & ~7) : k_end;
 
   bf16x8 ra[CH_A], rb[CH_B];
 
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
       const int c = tid + i * 256;
       if (AT) {
         const int row = c / (BM / 8), mc = c % (BM / 8);
-        const bool ok = (k0 + row < p.K) && (m0 + mc * 8 < M8);
+        const bool ok = (k0 + row < k_end) && (m0 + mc * 8 < M8);
         ra[i] = ok ? *reinterpret_cast<const bf16x8*>(Ag + (long)(k0 + row) * p.lda + m0 + mc * 8) : zero_bf16x8();
       } else {
         const int row = c / (BK / 8), kc = c % (BK / 8);
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
       const int c = tid + i * 256;
       if (BT) {
         const int row = c / (BN / 8), nc = c % (BN / 8);
-        const bool ok = (k0 + row < p.K) && (n0 + nc * 8 < N8);
+        const bool ok = (k0 + row < k_end) && (n0 + nc * 8 < N8);
         rb[i] = ok ? *reinterpret_cast<const bf16x8*>(Bg + (long)(k0 + row) * p.ldb + n0 + nc * 8) : zero_bf16x8();
       } else {
         const int row = c / (BK / 8), kc = c % (BK / 8);
@@ -115,14 +119,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tiles(0);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk <= 0) return;   // empty split (uniform for the whole block)
+  load_tiles(k_begin);
   store_tiles(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * BK);
     const bf16_t* sA = smem + cur * (A_ELEMS + B_ELEMS);
     const bf16_t* sB = sA + A_ELEMS;
 #pragma unroll
@@ -158,7 +163,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) go through
+  // LDS so that every thread then owns 4 consecutive columns of a row: residual / aux / mask loads and the C stores
+  // are 8- or 16-byte, fully coalesced accesses instead of 2- or 4-byte ones at a 32-lane stride.
+  constexpr int SC = BN + 4;
+  static_assert(BM * SC * 2 <= 2 * (A_ELEMS + B_ELEMS), "C tile must fit in the staging buffers");
+  float* sC = reinterpret_cast<float*>(smem);
+  auto stage = [&](const f32x16& av, const int mi, const int ni) {
+    float* base = sC + (wm * 32 * TM + mi * 32 + 4 * h) * SC + wn * 32 * TN + ni * 32 + r32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * SC] = av[r];
+  };
+  stage(acc[0][0], 0, 0);
+  if constexpr (TN > 1) stage(acc[0][1], 0, 1);
+  if constexpr (TM > 1) {
+    stage(acc[1][0], 1, 0);
+    if constexpr (TN > 1) stage(acc[1][1], 1, 1);
+  }
+  __syncthreads();
+
   float* __restrict__ Cg = p.C ? p.C + b1 * p.c_sb1 + b2 * p.c_sb2 : nullptr;
   bf16_t* __restrict__ Cbg = p.Cb ? p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 : nullptr;
   const float* __restrict__ Rg = p.residual ? p.residual + b1 * p.r_sb1 + b2 * p.r_sb2 : nullptr;
@@ -166,59 +189,94 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   const float* __restrict__ RVg = p.rowvec ? p.rowvec + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
   const float* __restrict__ RV2g = p.rowvec2 ? p.rowvec2 + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
   const bf16_t* __restrict__ AUXg = p.aux ? p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2 : nullptr;
-
-  // One explicit call per accumulator tile (a loop over acc[mi][ni] is too big for the unroller and would
-  // push the accumulators to scratch).
   const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
   const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
-  auto epi = [&](const f32x16& av, const int mi, const int ni) {
-    const int n = n0 + wn * 32 * TN + ni * 32 + r32;
-    const bool n_ok = n < p.N;
-    const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+  const bool first_split = blockIdx.y == 0;
+
+  constexpr int GROUPS = BM * BN / 4 / 256;
+#pragma unroll 4
+  for (int i = 0; i < GROUPS; ++i) {
+    const int g = tid + i * 256;
+    const int row = g / (BN / 4), c4 = (g % (BN / 4)) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= p.M || n >= p.N) continue;
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * SC + c4);
+    const int nv = min(4, p.N - n);
+    const bool vec = p.vec_ok && nv == 4;
+    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f}, aux[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && first_split) {
+      if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n); bias[0] = t[0]; bias[1] = t[1]; bias[2] = t[2]; bias[3] = t[3]; }
+      else for (int j = 0; j < nv; ++j) bias[j] = p.bias[n + j];
+    }
+    if (Rg && first_split) {
+      const float* rp = Rg + (long)m * p.ldr + n;
+      if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp); res[0] = t[0]; res[1] = t[1]; res[2] = t[2]; res[3] = t[3]; }
+      else for (int j = 0; j < nv; ++j) res[j] = rp[j];
+    }
+    if (AUXg) {
+      const bf16_t* ap = AUXg + (long)m * p.ldaux + n;
+      if (vec) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(ap); aux[0] = (float)t[0]; aux[1] = (float)t[1]; aux[2] = (float)t[2]; aux[3] = (float)t[3]; }
+      else for (int j = 0; j < nv; ++j) aux[j] = (float)ap[j];
+    }
+    const float rv = RVg ? RVg[m] : 0.f;
+    const float rv2 = RV2g ? 1.f / RV2g[m] : 1.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float v = av[r];
-      if (n_ok && m < p.M) {
-        if (p.epilogue == BMHRL_EPI_LINEAR) {
-          v = v * p.alpha + bias;
-          if (Mg && !Mg[(long)m * p.mask_sm + n]) v = NEG_MASK;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n);
-          if (Rg) v += Rg[(long)m * p.ldr + n];
-        } else if (p.epilogue == BMHRL_EPI_PROB) {
-          v = v * p.alpha;
-          if (Mg && !Mg[(long)m * p.mask_sm + n]) v = NEG_MASK;
-          v = __expf(v - RVg[m]) / RV2g[m];
-        } else if (p.epilogue == BMHRL_EPI_DSCORE) {
-          const float pr = (float)AUXg[(long)m * p.ldaux + n];
-          v = pr * (v - RVg[m]) * p.alpha;
-        } else {  // BMHRL_EPI_RELU_BWD
-          v = ((float)AUXg[(long)m * p.ldaux + n] > 0.f) ? v * p.alpha : 0.f;
-        }
-        if (Cg) {
-          float* dst = Cg + (long)m * p.ldc + n;
-          *dst = p.accumulate ? (*dst + v) : v;
-        }
-        if (Cbg) Cbg[(long)m * p.ldcb + n] = (bf16_t)v;
+    for (int j = 0; j < 4; ++j) {
+      if (j >= nv) break;
+      float x = v[j];
+      if (p.epilogue == BMHRL_EPI_LINEAR) {
+        x = x * p.alpha + bias[j];
+        if (Mg && !Mg[(long)m * p.mask_sm + n + j]) x = NEG_MASK;
+        if (p.relu) x = fmaxf(x, 0.f);
+        if (p.dropout_p > 0.f) x *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n + j);
+        x += res[j];
+      } else if (p.epilogue == BMHRL_EPI_PROB) {
+        x = x * p.alpha;
+        if (Mg && !Mg[(long)m * p.mask_sm + n + j]) x = NEG_MASK;
+        x = __expf(x - rv) * rv2;
+      } else if (p.epilogue == BMHRL_EPI_DSCORE) {
+        x = aux[j] * (x - rv) * p.alpha;
+      } else {  // BMHRL_EPI_RELU_BWD
+        x = aux[j] > 0.f ? x * p.alpha : 0.f;
+      }
+      v[j] = x;
+    }
+    if (Cg) {
+      float* dst = Cg + (long)m * p.ldc + n;
+      if (p.splits > 1) {
+        for (int j = 0; j < nv; ++j) atomicAdd(dst + j, v[j]);
+      } else if (vec) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (p.accumulate) { const f32x4 t = *reinterpret_cast<const f32x4*>(dst); o += t; }
+        *reinterpret_cast<f32x4*>(dst) = o;
+      } else {
+        for (int j = 0; j < nv; ++j) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
       }
     }
-  };
-  epi(acc[0][0], 0, 0);
-  if constexpr (TN > 1) epi(acc[0][1], 0, 1);
-  if constexpr (TM > 1) {
-    epi(acc[1][0], 1, 0);
-    if constexpr (TN > 1) epi(acc[1][1], 1, 1);
+    if (Cbg) {
+      bf16_t* dst = Cbg + (long)m * p.ldcb + n;
+      if (vec) {
+        bf16x4 o;
+        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      } else {
+        for (int j = 0; j < nv; ++j) dst[j] = (bf16_t)v[j];
+      }
+    }
   }
 }
 
 template <int TM, int TN>
-hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, hipStream_t s) {
+hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int splits, hipStream_t s) {
   GemmArgs p = a;
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
-  dim3 grid(p.tiles_m * tiles_n, 1, batch), block(256);
+  p.splits = splits;
+  const int ktiles = (a.K + BK - 1) / BK;
+  p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
+  dim3 grid(p.tiles_m * tiles_n, splits, batch), block(256);
   if (!a_trans && !b_trans) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, p);
   else if (!a_trans && b_trans) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, p);
   else if (a_trans && !b_trans) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, p);
@@ -259,10 +317,29 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
     a.drop_sm = d->N; a.drop_sb2 = (long)d->M * d->N; a.drop_sb1 = a.drop_sb2 * d->batch2;
   }
   const int batch = d->batch1 * d->batch2;
+  // vector (8/16-byte) epilogue accesses need aligned bases and leading dimensions
+  auto al = [](const void* q, uintptr_t a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
+  a.vec_ok = al(d->C, 16) && d->ldc % 4 == 0 && d->c_sb1 % 4 == 0 && d->c_sb2 % 4 == 0 && al(d->Cb, 8) && d->ldcb % 4 == 0 &&
+             d->cb_sb1 % 4 == 0 && d->cb_sb2 % 4 == 0 && al(d->residual, 16) && d->ldr % 4 == 0 && d->r_sb1 % 4 == 0 &&
+             d->r_sb2 % 4 == 0 && al(d->aux, 8) && d->ldaux % 4 == 0 && d->aux_sb1 % 4 == 0 && d->aux_sb2 % 4 == 0 &&
+             al(d->bias, 16);
   const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
+  const long small_tiles = (long)((d->M + 63) / 64) * ((d->N + 63) / 64) * batch;
+  // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight
+  // gradients dW = dY^T X.  Only plain fp32 outputs qualify and the caller must opt in (C zero-initialised).
+  int splits = 1;
+  const bool can_split = d->allow_split_k && d->C && !d->Cb && d->epilogue == BMHRL_EPI_LINEAR && !d->relu && !d->mask &&
+                         d->dropout_p == 0.f && !d->accumulate;
+  const bool big = big_tiles >= 256;
+  if (can_split && !big && small_tiles < 384) {
+    const int ktiles = (d->K + BK - 1) / BK;
+    splits = (int)((512 + small_tiles - 1) / small_tiles);
+    if (splits > ktiles / 4) splits = ktiles / 4;   // >= 256 of K per split
+    if (splits < 1) splits = 1;
+  }
   hipError_t e;
   // 128x128 tiles only when they still give every CU (256) a block; otherwise 64x64 tiles fill the chip better.
-  if (big_tiles >= 256) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, (hipStream_t)stream);
-  else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, (hipStream_t)stream);
+  if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, 1, (hipStream_t)stream);
+  else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   return hip_status(e);
 }

@@ -175,8 +175,9 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
     dev = dyb.device
     dw = db = None
     if need_dw:
-        dw = torch.empty(N, K, device=dev)
-        ops.gemm(dyb, xb, N, K, rows, lda=ldy, ldb=ldx, a_off=dy_off, b_off=x_off, a_trans=True, b_trans=True, C_f32=dw, ldc=K)
+        dw = torch.zeros(N, K, device=dev)   # zeroed: the long row reduction may run split-K with fp32 atomics
+        ops.gemm(dyb, xb, N, K, rows, lda=ldy, ldb=ldx, a_off=dy_off, b_off=x_off, a_trans=True, b_trans=True, C_f32=dw, ldc=K,
+                 allow_split_k=True)
     if need_db:
         db = torch.empty(N, device=dev)
         ops.colsum_bf16(dyb, ldy, db, False, rows, N, dy_off=dy_off)

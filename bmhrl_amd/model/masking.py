@@ -3,15 +3,16 @@ Plain comparisons on the tensors' own device (they feed the attention kernels as
 import torch
 
 
-def subsequent_mask(size):
-    """(1, size, size) lower-triangular byte mask.  reference model/masking.py:3-11"""
-    return torch.tril(torch.ones(1, size, size), 0).byte()
+def subsequent_mask(size, device=None):
+    """(1, size, size) lower-triangular byte mask, built on `device` (no host->device copy: the training step is
+    captured into a HIP graph).  reference model/masking.py:3-11"""
+    return torch.tril(torch.ones(1, size, size, dtype=torch.uint8, device=device), 0)
 
 
 def c_mask(trg, pad_idx):
     """key-padding & causal mask of a caption batch, (B, L, L).  reference :13-15"""
     pad = (trg != pad_idx).unsqueeze(-2)
-    return pad & subsequent_mask(trg.size(-1)).type_as(pad).to(trg.device)
+    return pad & subsequent_mask(trg.size(-1), trg.device).type_as(pad)
 
 
 def mask(src, trg, pad_idx, data_pad=0):

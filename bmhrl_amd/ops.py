@@ -31,7 +31,9 @@ def _need_cuda(*ts):
 
 
 def bf16_zeros(rows: int, cols: int, device) -> torch.Tensor:
-    """bf16 (rows, pad8(cols)) buffer with zeroed padding columns."""
+    """bf16 (rows, pad8(cols)) buffer with zeroed padding columns (no fill when there is no padding)."""
+    if cols % 8 == 0:
+        return torch.empty(rows, cols, dtype=torch.bfloat16, device=device)
     return torch.zeros(rows, pad8(cols), dtype=torch.bfloat16, device=device)
 
 
@@ -41,7 +43,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          C_bf16: Optional[torch.Tensor] = None, ldcb=0, cb_strides=(0, 0), cb_off=0,
          epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
-         aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0)) -> None:
+         aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False) -> None:
     """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
     _need_cuda(A, B, C_f32, C_bf16)
     d = _lib.GemmDesc()
@@ -52,6 +54,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.C = None if C_f32 is None else C_f32.data_ptr() + 4 * c_off; d.ldc = ldc; d.c_sb1, d.c_sb2 = c_strides
     d.Cb = None if C_bf16 is None else C_bf16.data_ptr() + 2 * cb_off; d.ldcb = ldcb; d.cb_sb1, d.cb_sb2 = cb_strides
     d.epilogue = epilogue; d.alpha = alpha; d.relu = int(relu); d.accumulate = int(accumulate)
+    d.allow_split_k = int(allow_split_k)
     d.bias = _p(bias)
     d.residual = _p(residual); d.ldr = ldr; d.r_sb1, d.r_sb2 = r_strides
     d.mask = _p(mask); d.mask_sb1 = mask_sb1; d.mask_sm = mask_sm

@@ -51,6 +51,7 @@ typedef struct bmhrl_gemm_desc {
   float alpha;
   int32_t relu;
   int32_t accumulate;                             /* C += v instead of C = v (fp32 output only) */
+  int32_t allow_split_k;                          /* C is zero-initialised: long reductions may be split (fp32 atomics) */
   const float* bias;                              /* [N] or NULL */
   const float* residual; int64_t ldr, r_sb1, r_sb2; /* fp32 [M][N] or NULL */
   const uint8_t* mask; int64_t mask_sb1, mask_sm; /* byte mask[b1][m*mask_sm + n], mask_sm may be 0 */
