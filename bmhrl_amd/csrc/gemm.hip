@@ -10,6 +10,9 @@
 // Block = 4 waves (2 x 2), each wave owns (32*TM) x (32*TN) of the (64*TM) x (64*TN) block tile, BK = 64.
 // Global -> register -> LDS staging is software pipelined one K-tile ahead (two LDS buffers, one barrier
 // per K-tile).  Roofline: MFMA-bound for the 1024-wide projections; HBM-bound for K <= 128.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/bmhrl_hip.h"
 
@@ -28,13 +31,13 @@ struct GemmArgs {
   const float* rowvec; const float* rowvec2; long rv_sb1, rv_sb2;
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
-  int tiles_m, splits, k_per_split, vec_ok;
+  int tiles_m, splits, k_per_split, vec_ok, dbg;
 };
 
 constexpr int BK = 64;
 
 template <int TM, int TN, bool AT, bool BT>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // LDS row strides (elements).  k-contiguous tiles: +8 (16 B) keeps ds_read_b128 conflict free;
   // transposed tiles ([k][m]): +32 (64 B) puts the 4 rows of a tr-read block on disjoint bank quarters.
@@ -45,6 +48,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   constexpr int CH_A = BM * BK / 8 / 256, CH_B = BN * BK / 8 / 256;  // 16-byte chunks per thread
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (A_ELEMS + B_ELEMS)];
 
+  if (p.dbg == 1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
@@ -62,53 +66,88 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int K8 = (k_end == p.K) ? ((p.K + 7) & ~7) : k_end;
 
-  bf16x8 ra[CH_A], rb[CH_B];
+  // Staging: global -> registers -> LDS with TWO register sets, so two K-tiles are in flight per block while a
+  // third is being multiplied out of LDS (one wave per SIMD at 128x128 cannot hide L2/HBM latency with a single
+  // tile in flight: measured ~4.6k cycles per 512-cycle MFMA phase).  Loads are unconditional from clamped,
+  // always-valid addresses (straight-line code lets the compiler count vmcnt instead of draining to 0); chunks
+  // outside the matrix are zeroed when they are written to LDS.
+  struct Regs { bf16x8 a[CH_A]; bf16x8 b[CH_B]; unsigned ok; };
+  Regs R0, R1;
 
-  auto load_tiles = [&](int k0) {
+  // per-thread static part of the chunk addresses
+  const bf16_t* pa[CH_A];
+  const bf16_t* pb[CH_B];
+  unsigned static_ok = 0;
+  int a_row[CH_A], a_col[CH_A], b_row[CH_B], b_col[CH_B];
+#pragma unroll
+  for (int i = 0; i < CH_A; ++i) {
+    const int c = tid + i * 256;
+    a_row[i] = AT ? c / (BM / 8) : c / (BK / 8);
+    a_col[i] = AT ? c % (BM / 8) : c % (BK / 8);
+    if (AT) {   // rows = k, cols = m
+      const int mcol = m0 + a_col[i] * 8;
+      if (mcol < M8) static_ok |= 1u << i;
+      pa[i] = Ag + min(mcol, M8 - 8);
+    } else {    // rows = m, cols = k
+      const int mrow = m0 + a_row[i];
+      if (mrow < p.M) static_ok |= 1u << i;
+      pa[i] = Ag + (long)min(mrow, p.M - 1) * p.lda;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CH_B; ++i) {
+    const int c = tid + i * 256;
+    b_row[i] = BT ? c / (BN / 8) : c / (BK / 8);
+    b_col[i] = BT ? c % (BN / 8) : c % (BK / 8);
+    if (BT) {
+      const int ncol = n0 + b_col[i] * 8;
+      if (ncol < N8) static_ok |= 1u << (8 + i);
+      pb[i] = Bg + min(ncol, N8 - 8);
+    } else {
+      const int nrow = n0 + b_row[i];
+      if (nrow < p.N) static_ok |= 1u << (8 + i);
+      pb[i] = Bg + (long)min(nrow, p.N - 1) * p.ldb;
+    }
+  }
+  const int Klast8 = ((p.K + 7) & ~7) - 8;   // last valid 8-wide chunk along a k-contiguous row
+
+  auto load_tiles = [&](int k0, Regs& R) {
+    unsigned ok = 0;
 #pragma unroll
     for (int i = 0; i < CH_A; ++i) {
-      const int c = tid + i * 256;
       if (AT) {
-        const int row = c / (BM / 8), mc = c % (BM / 8);
-        const bool ok = (k0 + row < k_end) && (m0 + mc * 8 < M8);
-        ra[i] = ok ? *reinterpret_cast<const bf16x8*>(Ag + (long)(k0 + row) * p.lda + m0 + mc * 8) : zero_bf16x8();
+        const int kr = k0 + a_row[i];
+        if (kr < k_end) ok |= 1u << i;
+        R.a[i] = *reinterpret_cast<const bf16x8*>(pa[i] + (long)min(kr, p.K - 1) * p.lda);
       } else {
-        const int row = c / (BK / 8), kc = c % (BK / 8);
-        const bool ok = (m0 + row < p.M) && (k0 + kc * 8 < K8);
-        ra[i] = ok ? *reinterpret_cast<const bf16x8*>(Ag + (long)(m0 + row) * p.lda + k0 + kc * 8) : zero_bf16x8();
+        const int kc = k0 + a_col[i] * 8;
+        if (kc < K8) ok |= 1u << i;
+        R.a[i] = *reinterpret_cast<const bf16x8*>(pa[i] + min(kc, Klast8));
       }
     }
 #pragma unroll
     for (int i = 0; i < CH_B; ++i) {
-      const int c = tid + i * 256;
       if (BT) {
-        const int row = c / (BN / 8), nc = c % (BN / 8);
-        const bool ok = (k0 + row < k_end) && (n0 + nc * 8 < N8);
-        rb[i] = ok ? *reinterpret_cast<const bf16x8*>(Bg + (long)(k0 + row) * p.ldb + n0 + nc * 8) : zero_bf16x8();
+        const int kr = k0 + b_row[i];
+        if (kr < k_end) ok |= 1u << (8 + i);
+        R.b[i] = *reinterpret_cast<const bf16x8*>(pb[i] + (long)min(kr, p.K - 1) * p.ldb);
       } else {
-        const int row = c / (BK / 8), kc = c % (BK / 8);
-        const bool ok = (n0 + row < p.N) && (k0 + kc * 8 < K8);
-        rb[i] = ok ? *reinterpret_cast<const bf16x8*>(Bg + (long)(n0 + row) * p.ldb + k0 + kc * 8) : zero_bf16x8();
+        const int kc = k0 + b_col[i] * 8;
+        if (kc < K8) ok |= 1u << (8 + i);
+        R.b[i] = *reinterpret_cast<const bf16x8*>(pb[i] + min(kc, Klast8));
       }
     }
+    R.ok = ok & static_ok;
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const Regs& R) {
     bf16_t* sA = smem + buf * (A_ELEMS + B_ELEMS);
     bf16_t* sB = sA + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < CH_A; ++i) {
-      const int c = tid + i * 256;
-      const int row = AT ? c / (BM / 8) : c / (BK / 8);
-      const int col = AT ? c % (BM / 8) : c % (BK / 8);
-      *reinterpret_cast<bf16x8*>(sA + row * SA + col * 8) = ra[i];
-    }
+    for (int i = 0; i < CH_A; ++i)
+      *reinterpret_cast<bf16x8*>(sA + a_row[i] * SA + a_col[i] * 8) = ((R.ok >> i) & 1u) ? R.a[i] : zero_bf16x8();
 #pragma unroll
-    for (int i = 0; i < CH_B; ++i) {
-      const int c = tid + i * 256;
-      const int row = BT ? c / (BN / 8) : c / (BK / 8);
-      const int col = BT ? c % (BN / 8) : c % (BK / 8);
-      *reinterpret_cast<bf16x8*>(sB + row * SB + col * 8) = rb[i];
-    }
+    for (int i = 0; i < CH_B; ++i)
+      *reinterpret_cast<bf16x8*>(sB + b_row[i] * SB + b_col[i] * 8) = ((R.ok >> (8 + i)) & 1u) ? R.b[i] : zero_bf16x8();
   };
 
   f32x16 acc[TM][TN];
@@ -119,15 +158,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (k_end - k_begin + BK - 1) / BK;
-  if (nk <= 0) return;   // empty split (uniform for the whole block)
-  load_tiles(k_begin);
-  store_tiles(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * BK);
+  auto compute = [&](int cur) {
     const bf16_t* sA = smem + cur * (A_ELEMS + B_ELEMS);
     const bf16_t* sB = sA + A_ELEMS;
 #pragma unroll
@@ -159,13 +190,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int ni = 0; ni < TN; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
+  };
+
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk <= 0 || p.dbg == 2) return;   // empty split (uniform for the whole block)
+  // tile t lives in register set (t & 1) until it is written to LDS buffer (t & 1)
+  load_tiles(k_begin, R0);
+  if (nk > 1) load_tiles(k_begin + BK, R1);
+  store_tiles(0, R0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even tile: compute LDS[0]; R0 is free -> prefetch tile kt+2; then publish tile kt+1 (R1) to LDS[1]
+    if (kt + 2 < nk) load_tiles(k_begin + (kt + 2) * BK, R0);
+    compute(0);
+    if (kt + 1 < nk) store_tiles(1, R1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd tile: compute LDS[1]; R1 is free -> prefetch tile kt+3; then publish tile kt+2 (R0) to LDS[0]
+    if (kt + 3 < nk) load_tiles(k_begin + (kt + 3) * BK, R1);
+    compute(1);
+    if (kt + 2 < nk) store_tiles(0, R0);
     __syncthreads();
   }
 
   // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) go through
   // LDS so that every thread then owns 4 consecutive columns of a row: residual / aux / mask loads and the C stores
   // are 8- or 16-byte, fully coalesced accesses instead of 2- or 4-byte ones at a 32-lane stride.
+  if (p.dbg == 3) { if (acc[0][0][0] == 123.f) p.C[0] = 1.f; return; }
   constexpr int SC = BN + 4;
   static_assert(BM * SC * 2 <= 2 * (A_ELEMS + B_ELEMS), "C tile must fit in the staging buffers");
   float* sC = reinterpret_cast<float*>(smem);
@@ -192,79 +243,94 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
   const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
   const bool first_split = blockIdx.y == 0;
+  const float* __restrict__ biasp = first_split ? p.bias : nullptr;
+  if (!first_split) Rg = nullptr;
+
+  // element-wise part, one variant per epilogue kind (KIND: 0 plain linear, 1 linear with mask / dropout, 2 PROB,
+  // 3 DSCORE, 4 RELU_BWD); x = accumulator, returns the output value
+  auto elem = [&](auto kind, float x, float bias, float res, float aux, float rv, float rv2, int m, int n) -> float {
+    constexpr int KIND = decltype(kind)::value;
+    if constexpr (KIND == 0) {
+      x = x * p.alpha + bias;
+      if (p.relu) x = fmaxf(x, 0.f);
+      return x + res;
+    } else if constexpr (KIND == 1) {
+      x = x * p.alpha + bias;
+      if (Mg && !Mg[(long)m * p.mask_sm + n]) x = NEG_MASK;
+      if (p.relu) x = fmaxf(x, 0.f);
+      if (p.dropout_p > 0.f) x *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n);
+      return x + res;
+    } else if constexpr (KIND == 2) {
+      x = x * p.alpha;
+      if (Mg && !Mg[(long)m * p.mask_sm + n]) x = NEG_MASK;
+      return __expf(x - rv) * rv2;
+    } else if constexpr (KIND == 3) {
+      return aux * (x - rv) * p.alpha;
+    } else {
+      return aux > 0.f ? x * p.alpha : 0.f;
+    }
+  };
 
   constexpr int GROUPS = BM * BN / 4 / 256;
+  auto run = [&](auto kind) {
 #pragma unroll 4
-  for (int i = 0; i < GROUPS; ++i) {
-    const int g = tid + i * 256;
-    const int row = g / (BN / 4), c4 = (g % (BN / 4)) * 4;
-    const int m = m0 + row, n = n0 + c4;
-    if (m >= p.M || n >= p.N) continue;
-    const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * SC + c4);
-    const int nv = min(4, p.N - n);
-    const bool vec = p.vec_ok && nv == 4;
-    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-    float bias[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f}, aux[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && first_split) {
-      if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n); bias[0] = t[0]; bias[1] = t[1]; bias[2] = t[2]; bias[3] = t[3]; }
-      else for (int j = 0; j < nv; ++j) bias[j] = p.bias[n + j];
-    }
-    if (Rg && first_split) {
-      const float* rp = Rg + (long)m * p.ldr + n;
-      if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp); res[0] = t[0]; res[1] = t[1]; res[2] = t[2]; res[3] = t[3]; }
-      else for (int j = 0; j < nv; ++j) res[j] = rp[j];
-    }
-    if (AUXg) {
-      const bf16_t* ap = AUXg + (long)m * p.ldaux + n;
-      if (vec) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(ap); aux[0] = (float)t[0]; aux[1] = (float)t[1]; aux[2] = (float)t[2]; aux[3] = (float)t[3]; }
-      else for (int j = 0; j < nv; ++j) aux[j] = (float)ap[j];
-    }
-    const float rv = RVg ? RVg[m] : 0.f;
-    const float rv2 = RV2g ? 1.f / RV2g[m] : 1.f;
+    for (int i = 0; i < GROUPS; ++i) {
+      const int g = tid + i * 256;
+      const int row = g / (BN / 4), c4 = (g % (BN / 4)) * 4;
+      const int m = m0 + row, n = n0 + c4;
+      if (m < p.M && n < p.N) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * SC + c4);
+        const float rv = RVg ? RVg[m] : 0.f;
+        const float rv2 = RV2g ? 1.f / RV2g[m] : 1.f;
+        if (p.vec_ok && n + 4 <= p.N) {
+          f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = {0.f, 0.f, 0.f, 0.f}, x4 = {0.f, 0.f, 0.f, 0.f};
+          if (biasp) b4 = *reinterpret_cast<const f32x4*>(biasp + n);
+          if (Rg) r4 = *reinterpret_cast<const f32x4*>(Rg + (long)m * p.ldr + n);
+          if (AUXg) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(AUXg + (long)m * p.ldaux + n);
+            x4[0] = (float)t[0]; x4[1] = (float)t[1]; x4[2] = (float)t[2]; x4[3] = (float)t[3];
+          }
+          f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j >= nv) break;
-      float x = v[j];
-      if (p.epilogue == BMHRL_EPI_LINEAR) {
-        x = x * p.alpha + bias[j];
-        if (Mg && !Mg[(long)m * p.mask_sm + n + j]) x = NEG_MASK;
-        if (p.relu) x = fmaxf(x, 0.f);
-        if (p.dropout_p > 0.f) x *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n + j);
-        x += res[j];
-      } else if (p.epilogue == BMHRL_EPI_PROB) {
-        x = x * p.alpha;
-        if (Mg && !Mg[(long)m * p.mask_sm + n + j]) x = NEG_MASK;
-        x = __expf(x - rv) * rv2;
-      } else if (p.epilogue == BMHRL_EPI_DSCORE) {
-        x = aux[j] * (x - rv) * p.alpha;
-      } else {  // BMHRL_EPI_RELU_BWD
-        x = aux[j] > 0.f ? x * p.alpha : 0.f;
-      }
-      v[j] = x;
-    }
-    if (Cg) {
-      float* dst = Cg + (long)m * p.ldc + n;
-      if (p.splits > 1) {
-        for (int j = 0; j < nv; ++j) atomicAdd(dst + j, v[j]);
-      } else if (vec) {
-        f32x4 o = {v[0], v[1], v[2], v[3]};
-        if (p.accumulate) { const f32x4 t = *reinterpret_cast<const f32x4*>(dst); o += t; }
-        *reinterpret_cast<f32x4*>(dst) = o;
-      } else {
-        for (int j = 0; j < nv; ++j) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
-      }
-    }
-    if (Cbg) {
-      bf16_t* dst = Cbg + (long)m * p.ldcb + n;
-      if (vec) {
-        bf16x4 o;
-        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-        *reinterpret_cast<bf16x4*>(dst) = o;
-      } else {
-        for (int j = 0; j < nv; ++j) dst[j] = (bf16_t)v[j];
+          for (int j = 0; j < 4; ++j) o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j);
+          if (Cg) {
+            float* dst = Cg + (long)m * p.ldc + n;
+            if (p.splits > 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) atomicAdd(dst + j, o[j]);
+            } else {
+              if (p.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+              *reinterpret_cast<f32x4*>(dst) = o;
+            }
+          }
+          if (Cbg) {
+            bf16x4 ob;
+            ob[0] = (bf16_t)o[0]; ob[1] = (bf16_t)o[1]; ob[2] = (bf16_t)o[2]; ob[3] = (bf16_t)o[3];
+            *reinterpret_cast<bf16x4*>(Cbg + (long)m * p.ldcb + n) = ob;
+          }
+        } else {   // ragged right edge or unaligned operands: scalar accesses
+          for (int j = 0; j < 4 && n + j < p.N; ++j) {
+            const float b = biasp ? biasp[n + j] : 0.f;
+            const float r = Rg ? Rg[(long)m * p.ldr + n + j] : 0.f;
+            const float ax = AUXg ? (float)AUXg[(long)m * p.ldaux + n + j] : 0.f;
+            const float o = elem(kind, a4[j], b, r, ax, rv, rv2, m, n + j);
+            if (Cg) {
+              float* dst = Cg + (long)m * p.ldc + n + j;
+              if (p.splits > 1) atomicAdd(dst, o);
+              else *dst = p.accumulate ? *dst + o : o;
+            }
+            if (Cbg) Cbg[(long)m * p.ldcb + n + j] = (bf16_t)o;
+          }
+        }
       }
     }
-  }
+  };
+  if (p.epilogue == BMHRL_EPI_LINEAR) {
+    if (!Mg && p.dropout_p == 0.f) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+  } else if (p.epilogue == BMHRL_EPI_PROB) run(std::integral_constant<int, 2>{});
+  else if (p.epilogue == BMHRL_EPI_DSCORE) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, 4>{});
 }
 
 template <int TM, int TN>
@@ -274,6 +340,7 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
   p.tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
   p.splits = splits;
+  p.dbg = getenv("BMHRL_GEMM_DBG") ? atoi(getenv("BMHRL_GEMM_DBG")) : 0;
   const int ktiles = (a.K + BK - 1) / BK;
   p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
   dim3 grid(p.tiles_m * tiles_n, splits, batch), block(256);
@@ -330,7 +397,9 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   int splits = 1;
   const bool can_split = d->allow_split_k && d->C && !d->Cb && d->epilogue == BMHRL_EPI_LINEAR && !d->relu && !d->mask &&
                          d->dropout_p == 0.f && !d->accumulate;
-  const bool big = big_tiles >= 256;
+  static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
+  static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
+  const bool big = force_tile ? force_tile == 2 : big_tiles >= big_min;
   if (can_split && !big && small_tiles < 384) {
     const int ktiles = (d->K + BK - 1) / BK;
     splits = (int)((512 + small_tiles - 1) / small_tiles);
