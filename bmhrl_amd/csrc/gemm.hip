@@ -66,88 +66,64 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int K8 = (k_end == p.K) ? ((p.K + 7) & ~7) : k_end;
 
-  // Staging: global -> registers -> LDS with TWO register sets, so two K-tiles are in flight per block while a
-  // third is being multiplied out of LDS (one wave per SIMD at 128x128 cannot hide L2/HBM latency with a single
-  // tile in flight: measured ~4.6k cycles per 512-cycle MFMA phase).  Loads are unconditional from clamped,
-  // always-valid addresses (straight-line code lets the compiler count vmcnt instead of draining to 0); chunks
-  // outside the matrix are zeroed when they are written to LDS.
-  struct Regs { bf16x8 a[CH_A]; bf16x8 b[CH_B]; unsigned ok; };
-  Regs R0, R1;
-
-  // per-thread static part of the chunk addresses
-  const bf16_t* pa[CH_A];
-  const bf16_t* pb[CH_B];
-  unsigned static_ok = 0;
-  int a_row[CH_A], a_col[CH_A], b_row[CH_B], b_col[CH_B];
+  // Staging: global -> registers -> LDS, one K-tile ahead (two LDS buffers, one barrier per tile; a second
+  // co-resident block per CU covers this block's load latency).  The hot loop carries no bounds logic: each chunk
+  // has a constant 32-bit element offset from a uniform base that advances by one K-tile per iteration (rows /
+  // columns past the matrix edge are clamped to valid memory and only feed outputs that are never stored); only
+  // the last, ragged K-tile of a reduction is loaded through the masked path that zero-fills k >= K.
+  bf16x8 ra[CH_A], rb[CH_B];
+  int a_off[CH_A], b_off[CH_B], a_lds[CH_A], b_lds[CH_B], a_kk[CH_A], b_kk[CH_B];
 #pragma unroll
   for (int i = 0; i < CH_A; ++i) {
     const int c = tid + i * 256;
-    a_row[i] = AT ? c / (BM / 8) : c / (BK / 8);
-    a_col[i] = AT ? c % (BM / 8) : c % (BK / 8);
-    if (AT) {   // rows = k, cols = m
-      const int mcol = m0 + a_col[i] * 8;
-      if (mcol < M8) static_ok |= 1u << i;
-      pa[i] = Ag + min(mcol, M8 - 8);
-    } else {    // rows = m, cols = k
-      const int mrow = m0 + a_row[i];
-      if (mrow < p.M) static_ok |= 1u << i;
-      pa[i] = Ag + (long)min(mrow, p.M - 1) * p.lda;
-    }
+    const int row = AT ? c / (BM / 8) : c / (BK / 8), col = AT ? c % (BM / 8) : c % (BK / 8);
+    a_lds[i] = row * SA + col * 8;
+    a_kk[i] = AT ? row : col * 8;                                   // k index of this chunk inside a tile
+    a_off[i] = AT ? min(m0 + col * 8, M8 - 8) : min(m0 + row, p.M - 1) * (int)p.lda;
   }
 #pragma unroll
   for (int i = 0; i < CH_B; ++i) {
     const int c = tid + i * 256;
-    b_row[i] = BT ? c / (BN / 8) : c / (BK / 8);
-    b_col[i] = BT ? c % (BN / 8) : c % (BK / 8);
-    if (BT) {
-      const int ncol = n0 + b_col[i] * 8;
-      if (ncol < N8) static_ok |= 1u << (8 + i);
-      pb[i] = Bg + min(ncol, N8 - 8);
-    } else {
-      const int nrow = n0 + b_row[i];
-      if (nrow < p.N) static_ok |= 1u << (8 + i);
-      pb[i] = Bg + (long)min(nrow, p.N - 1) * p.ldb;
-    }
+    const int row = BT ? c / (BN / 8) : c / (BK / 8), col = BT ? c % (BN / 8) : c % (BK / 8);
+    b_lds[i] = row * SB + col * 8;
+    b_kk[i] = BT ? row : col * 8;
+    b_off[i] = BT ? min(n0 + col * 8, N8 - 8) : min(n0 + row, p.N - 1) * (int)p.ldb;
   }
   const int Klast8 = ((p.K + 7) & ~7) - 8;   // last valid 8-wide chunk along a k-contiguous row
 
-  auto load_tiles = [&](int k0, Regs& R) {
-    unsigned ok = 0;
+  auto load_fast = [&](int k0) {   // every k of the tile is < K
+    const bf16_t* Ak = Ag + (AT ? (long)k0 * p.lda : (long)k0);
+    const bf16_t* Bk = Bg + (BT ? (long)k0 * p.ldb : (long)k0);
+#pragma unroll
+    for (int i = 0; i < CH_A; ++i) ra[i] = *reinterpret_cast<const bf16x8*>(Ak + a_off[i] + (AT ? a_kk[i] * (int)p.lda : a_kk[i]));
+#pragma unroll
+    for (int i = 0; i < CH_B; ++i) rb[i] = *reinterpret_cast<const bf16x8*>(Bk + b_off[i] + (BT ? b_kk[i] * (int)p.ldb : b_kk[i]));
+  };
+  auto load_tail = [&](int k0) {   // ragged last tile: clamp, then zero what lies at k >= K
 #pragma unroll
     for (int i = 0; i < CH_A; ++i) {
-      if (AT) {
-        const int kr = k0 + a_row[i];
-        if (kr < k_end) ok |= 1u << i;
-        R.a[i] = *reinterpret_cast<const bf16x8*>(pa[i] + (long)min(kr, p.K - 1) * p.lda);
-      } else {
-        const int kc = k0 + a_col[i] * 8;
-        if (kc < K8) ok |= 1u << i;
-        R.a[i] = *reinterpret_cast<const bf16x8*>(pa[i] + min(kc, Klast8));
-      }
+      const int k = k0 + a_kk[i];
+      const bool ok = AT ? (k < k_end) : (k < K8);
+      const bf16_t* q = AT ? Ag + (long)min(k, p.K - 1) * p.lda + a_off[i] : Ag + a_off[i] + min(k, Klast8);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(q);
+      ra[i] = ok ? v : zero_bf16x8();
     }
 #pragma unroll
     for (int i = 0; i < CH_B; ++i) {
-      if (BT) {
-        const int kr = k0 + b_row[i];
-        if (kr < k_end) ok |= 1u << (8 + i);
-        R.b[i] = *reinterpret_cast<const bf16x8*>(pb[i] + (long)min(kr, p.K - 1) * p.ldb);
-      } else {
-        const int kc = k0 + b_col[i] * 8;
-        if (kc < K8) ok |= 1u << (8 + i);
-        R.b[i] = *reinterpret_cast<const bf16x8*>(pb[i] + min(kc, Klast8));
-      }
+      const int k = k0 + b_kk[i];
+      const bool ok = BT ? (k < k_end) : (k < K8);
+      const bf16_t* q = BT ? Bg + (long)min(k, p.K - 1) * p.ldb + b_off[i] : Bg + b_off[i] + min(k, Klast8);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(q);
+      rb[i] = ok ? v : zero_bf16x8();
     }
-    R.ok = ok & static_ok;
   };
-  auto store_tiles = [&](int buf, const Regs& R) {
+  auto store_tiles = [&](int buf) {
     bf16_t* sA = smem + buf * (A_ELEMS + B_ELEMS);
     bf16_t* sB = sA + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < CH_A; ++i)
-      *reinterpret_cast<bf16x8*>(sA + a_row[i] * SA + a_col[i] * 8) = ((R.ok >> i) & 1u) ? R.a[i] : zero_bf16x8();
+    for (int i = 0; i < CH_A; ++i) *reinterpret_cast<bf16x8*>(sA + a_lds[i]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < CH_B; ++i)
-      *reinterpret_cast<bf16x8*>(sB + b_row[i] * SB + b_col[i] * 8) = ((R.ok >> (8 + i)) & 1u) ? R.b[i] : zero_bf16x8();
+    for (int i = 0; i < CH_B; ++i) *reinterpret_cast<bf16x8*>(sB + b_lds[i]) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -194,22 +170,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
   if (nk <= 0 || p.dbg == 2) return;   // empty split (uniform for the whole block)
-  // tile t lives in register set (t & 1) until it is written to LDS buffer (t & 1)
-  load_tiles(k_begin, R0);
-  if (nk > 1) load_tiles(k_begin + BK, R1);
-  store_tiles(0, R0);
+  const bool ragged = (k_end - k_begin) % BK != 0;         // the last tile holds k >= K (zero-filled)
+  auto load_any = [&](int t) {
+    if (ragged && t == nk - 1) load_tail(k_begin + t * BK);
+    else load_fast(k_begin + t * BK);
+  };
+  load_any(0);
+  store_tiles(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    // even tile: compute LDS[0]; R0 is free -> prefetch tile kt+2; then publish tile kt+1 (R1) to LDS[1]
-    if (kt + 2 < nk) load_tiles(k_begin + (kt + 2) * BK, R0);
-    compute(0);
-    if (kt + 1 < nk) store_tiles(1, R1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    // odd tile: compute LDS[1]; R1 is free -> prefetch tile kt+3; then publish tile kt+2 (R0) to LDS[0]
-    if (kt + 3 < nk) load_tiles(k_begin + (kt + 3) * BK, R1);
-    compute(1);
-    if (kt + 2 < nk) store_tiles(0, R0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_any(kt + 1);
+    compute(cur);
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
@@ -325,6 +298,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
       }
     }
   };
+  if (p.splits > 1) {
+    // split-K partial sums: lane l adds column l of a row, so one wave instruction covers 256 contiguous bytes (the
+    // shape float atomics run at full rate with); bias / residual are added by the first split only.
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int row = idx / BN, col = idx % BN;
+      const int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) {
+        float x = sC[row * SC + col] * p.alpha;
+        if (biasp) x += biasp[n];
+        if (Rg) x += Rg[(long)m * p.ldr + n];
+        atomicAdd(Cg + (long)m * p.ldc + n, x);
+      }
+    }
+    return;
+  }
   if (p.epilogue == BMHRL_EPI_LINEAR) {
     if (!Mg && p.dropout_p == 0.f) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
@@ -399,8 +387,16 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
                          d->dropout_p == 0.f && !d->accumulate;
   static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
   static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
-  const bool big = force_tile ? force_tile == 2 : big_tiles >= big_min;
-  if (can_split && !big && small_tiles < 384) {
+  bool big = force_tile ? force_tile == 2 : big_tiles >= big_min;
+  if (can_split && !force_tile && d->M >= 128 && d->N >= 128 && big_tiles <= 96 && d->K >= 1024) {
+    // weight gradients with a small output and a long reduction: 128x128 tiles (about 3x the rate of 64x64 ones),
+    // the chip is filled through the K split
+    const int ktiles = (d->K + BK - 1) / BK;
+    int s2 = (int)((256 + big_tiles - 1) / big_tiles);
+    if (s2 > ktiles / 4) s2 = ktiles / 4;
+    if (s2 >= 2) { big = true; splits = s2; }
+  }
+  if (splits == 1 && can_split && !big && small_tiles < 192) {
     const int ktiles = (d->K + BK - 1) / BK;
     splits = (int)((512 + small_tiles - 1) / small_tiles);
     if (splits > ktiles / 4) splits = ktiles / 4;   // >= 256 of K per split
@@ -408,7 +404,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   }
   hipError_t e;
   // 128x128 tiles only when they still give every CU (256) a block; otherwise 64x64 tiles fill the chip better.
-  if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, 1, (hipStream_t)stream);
+  if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   return hip_status(e);
 }
