@@ -46,8 +46,16 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   static_assert(BN * (DK / 8) % NT == 0, "tile must divide evenly");
   constexpr int MERGE_FLOATS = (KW > 1) ? (KW - 1) * QW * 130 * 64 : 0;
   constexpr int LDS_BYTES = (2 * STAGE * 2 > MERGE_FLOATS * 4) ? 2 * STAGE * 2 : MERGE_FLOATS * 4;
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES];
+  // per-key softmax coefficients of this batch row: score2 = fma(q.k, coef[key], pen[key]) in the log2 domain
+  //   valid key  : coef = scale*log2(e), pen = 0        masked key : coef = 0, pen = -1e9*log2(e)
+  //   key >= Sk  : coef = 0, pen = -inf  (tile padding)
+  constexpr int MAXK = 2048 + 64;
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES + 2 * MAXK * 4];
+  float* s_coef = reinterpret_cast<float*>(smem_raw + LDS_BYTES);
+  float* s_pen = s_coef + MAXK;
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  constexpr float RESCALE_THR = 8.f;   // lazy rescale: keep a stale running max while it lags by < 2^8
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = wave / KW, ki = wave % KW;
@@ -63,6 +71,16 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   const bf16_t* __restrict__ Kg = p.K + (long)b * p.Sk * p.ldk + hd * DK;
   const bf16_t* __restrict__ Vg = p.V + (long)b * p.Sk * p.ldv + hd * DK;
 
+  const bool key_mask = p.mask == nullptr || p.mask_sq == 0;    // same mask for every query row -> LDS coefficients
+  const int padded = ((p.Sk + BN - 1) / BN) * BN;
+  for (int i = tid; i < padded; i += NT) {
+    const bool in = i < p.Sk;
+    const bool keep = in && (!key_mask || p.mask == nullptr || p.mask[(long)b * p.mask_sb + i] != 0);
+    s_coef[i] = (in && (keep || !key_mask)) ? p.scale * LOG2E : 0.f;
+    s_pen[i] = in ? ((keep || !key_mask) ? 0.f : NEG_MASK * LOG2E) : -INFINITY;
+  }
+  const uint8_t* __restrict__ mrow = (!key_mask) ? p.mask + (long)b * p.mask_sb + (long)(q_ok ? q_row : 0) * p.mask_sq : nullptr;
+
   // Q^T fragments: lane (q = r32, h) holds Q[q][16*step + 8h .. +8)
   bf16x8 qf[DK / 16];
   {
@@ -71,15 +89,31 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     for (int s = 0; s < DK / 16; ++s) qf[s] = q_ok ? *reinterpret_cast<const bf16x8*>(qp + 16 * s) : zero_bf16x8();
   }
 
+  // K/V staging: constant per-chunk offsets from a uniform tile base (no per-tile address arithmetic); only the
+  // last, ragged tile clamps its rows (keys past Sk get pen = -inf, so P is exactly 0 there and the clamped, finite
+  // V rows contribute nothing).
   bf16x8 rk[CH], rv[CH];
+  static_assert(NT % (DK / 8) == 0, "a thread keeps its column; rows advance by NT / (DK/8) per chunk");
+  constexpr int RSTEP = NT / (DK / 8);                       // rows between consecutive chunks of one thread
+  const int row0 = tid / (DK / 8), col8 = (tid % (DK / 8)) * 8;
+  const int koff0 = row0 * (int)p.ldk + col8, voff0 = row0 * (int)p.ldv + col8;
+  const int lk0 = row0 * SKS + col8, lv0 = row0 * SVS + col8;
   auto load_tile = [&](int k0) {
+    const bf16_t* Kt = Kg + (long)k0 * p.ldk;
+    const bf16_t* Vt = Vg + (long)k0 * p.ldv;
+    if (k0 + BN <= p.Sk) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / (DK / 8), col = c % (DK / 8);
-      const bool ok = (k0 + row) < p.Sk;
-      rk[i] = ok ? *reinterpret_cast<const bf16x8*>(Kg + (long)(k0 + row) * p.ldk + col * 8) : zero_bf16x8();
-      rv[i] = ok ? *reinterpret_cast<const bf16x8*>(Vg + (long)(k0 + row) * p.ldv + col * 8) : zero_bf16x8();
+      for (int i = 0; i < CH; ++i) {
+        rk[i] = *reinterpret_cast<const bf16x8*>(Kt + (long)i * RSTEP * p.ldk + koff0);
+        rv[i] = *reinterpret_cast<const bf16x8*>(Vt + (long)i * RSTEP * p.ldv + voff0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int r = min(k0 + row0 + i * RSTEP, p.Sk - 1);   // clamp to the last key row
+        rk[i] = *reinterpret_cast<const bf16x8*>(Kg + (long)r * p.ldk + col8);
+        rv[i] = *reinterpret_cast<const bf16x8*>(Vg + (long)r * p.ldv + col8);
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -87,10 +121,8 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     bf16_t* sV = sK + K_ELEMS;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / (DK / 8), col = c % (DK / 8);
-      *reinterpret_cast<bf16x8*>(sK + row * SKS + col * 8) = rk[i];
-      *reinterpret_cast<bf16x8*>(sV + row * SVS + col * 8) = rv[i];
+      *reinterpret_cast<bf16x8*>(sK + lk0 + i * RSTEP * SKS) = rk[i];
+      *reinterpret_cast<bf16x8*>(sV + lv0 + i * RSTEP * SVS) = rv[i];
     }
   };
 
@@ -99,9 +131,7 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   for (int d = 0; d < DK / 32; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const uint8_t* __restrict__ mrow = p.mask ? p.mask + (long)b * p.mask_sb + (long)(q_ok ? q_row : 0) * p.mask_sq : nullptr;
+  float m_run = -INFINITY, l_run = 0.f;   // log2-domain running max (possibly stale by < RESCALE_THR) and sum
 
   const int nt = (p.Sk + BN - 1) / BN;
   load_tile(0);
@@ -126,38 +156,50 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
     }
 
-    // ---- masked, scaled scores; online softmax (per-lane state: this lane's query row)
+    // ---- log2-domain scores: one FMA per element with the per-key coefficient / penalty (4 consecutive keys per
+    // 16-byte LDS read); then the online softmax on per-lane state (this lane's query row)
     const int key0 = k0 + 32 * ki + 4 * h;
     float m_tile = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = key0 + (r & 3) + 8 * (r >> 2);
-      float v = s[r] * p.scale;
-      if (mrow && key < p.Sk && !mrow[key]) v = NEG_MASK;
-      if (key >= p.Sk) v = -INFINITY;
-      s[r] = v;
-      m_tile = fmaxf(m_tile, v);
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 cf = *reinterpret_cast<const f32x4*>(s_coef + key0 + 8 * g);
+      const f32x4 pn = *reinterpret_cast<const f32x4*>(s_pen + key0 + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = fmaf(s[4 * g + j], cf[j], pn[j]);
+        if (mrow) {   // per-query mask (not the encoder's case): exact masked_fill semantics from global memory
+          const int key = key0 + 8 * g + j;
+          if (key < p.Sk && !mrow[key]) v = NEG_MASK * LOG2E;
+        }
+        s[4 * g + j] = v;
+        m_tile = fmaxf(m_tile, v);
+      }
     }
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_safe);
+    // lazy rescale (only when some row's max grew by more than RESCALE_THR): everything accumulated so far is at
+    // the old max and P of this tile has not been exponentiated yet, so O and l are scaled exactly once
+    if (__any(m_tile > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      if (t > 0) {
+#pragma unroll
+        for (int d = 0; d < DK / 32; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
+      m_run = m_new;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(s[r] - m_safe);
+      const float e = __builtin_amdgcn_exp2f(s[r] - m_use);
       s[r] = e;
       psum += e;
     }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (__any(alpha != 1.f)) {
-#pragma unroll
-      for (int d = 0; d < DK / 32; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
+    l_run += psum;
     bf16x8 pf[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -202,7 +244,7 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
         const float m2 = src[128 * 64], l2 = src[129 * 64];
         const float m = fmaxf(m_run, m2);
         const float ms = (m == -INFINITY) ? 0.f : m;
-        const float a1 = __expf(m_run - ms), a2 = __expf(m2 - ms);
+        const float a1 = __builtin_amdgcn_exp2f(m_run - ms), a2 = __builtin_amdgcn_exp2f(m2 - ms);
 #pragma unroll
         for (int d = 0; d < DK / 32; ++d)
 #pragma unroll
@@ -217,7 +259,9 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     const float inv = 1.0f / l_run;
     if (h == 0) {
       const long si = ((long)b * p.H + hd) * p.Sq + q_row;
-      p.row_max[si] = m_run;
+      // statistics in natural-log units: P = exp(score - row_max) / row_sum.  A fully masked row keeps the exact
+      // fill value so that the backward recomputation exp(-1e9 - row_max) is exp(0).
+      p.row_max[si] = (m_run <= NEG_MASK * LOG2E) ? NEG_MASK : m_run * LN2;
       p.row_sum[si] = l_run;
     }
     bf16_t* op = p.O + ((long)b * p.Sq + q_row) * p.ldo + hd * DK + 4 * h;
@@ -292,7 +336,7 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
                                    bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(Q && K && V && O && row_max && row_sum);
   BMHRL_CHECK_ARG(dk == DK);  // d_model 1024 / H 4 of the reference; other head sizes use the materialised path
-  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
+  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 2048);
   BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
   BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldk >= (int64_t)H * DK && ldv >= (int64_t)H * DK && ldo >= (int64_t)H * DK);
   BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && ((uintptr_t)O & 7) == 0);

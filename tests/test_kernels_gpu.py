@@ -183,10 +183,14 @@ def test_attention_fwd(dev, B, H, Sq, Sk, kind):
     torch.cuda.synchronize()
     ref, s = _attn_ref(Q, K, V, mask, H, scale)
     assert rel_err(O.float(), ref) < 1.5e-2  # bf16 P and bf16 output
-    m_ref = s.max(-1).values
-    l_ref = torch.exp(s - m_ref[..., None]).sum(-1)
-    assert rel_err(rmax, m_ref) < 1e-5
-    assert rel_err(rsum, l_ref) < 2e-3
+    # (row_max, row_sum) are any consistent pair with P = exp(s - row_max) / row_sum (the kernel keeps a running max
+    # that may lag the true one by a bounded amount); compare the log-sum-exp and the reconstructed probabilities
+    lse_ref = torch.logsumexp(s, -1)
+    lse = rmax.double().cpu() + torch.log(rsum.double().cpu())
+    assert float((lse - lse_ref.cpu()).abs().max()) < 2e-3 * max(1.0, float(lse_ref.abs().max()) * 1e-6 + 1.0)
+    p_rec = torch.exp(s.cpu() - rmax.double().cpu()[..., None]) / rsum.double().cpu()[..., None]
+    assert float((p_rec - torch.softmax(s, -1).cpu()).abs().max()) < 2e-3
+    assert float((s.max(-1).values.cpu() - rmax.double().cpu()).max()) < 8 * 0.6932 + 1e-3   # lag bound (2^8)
     if kind == "allmasked":  # uniform attention over all Sk keys (reference fills -1e9, not -inf)
         assert rel_err(O.float(), V.float().view(B, Sk, D).mean(1, keepdim=True).expand(B, Sq, D)) < 1.5e-2
 
