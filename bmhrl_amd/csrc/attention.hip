@@ -21,8 +21,12 @@
 namespace {
 
 constexpr int DK = 256;
-constexpr int SKS = DK + 8;   // K tile row stride (elements): +16 B -> conflict-free ds_read_b128 across 16 rows
-constexpr int SVS = DK + 32;  // V tile row stride: +64 B -> the 4 rows of a tr-read block hit disjoint bank quarters
+// K / V tiles sit in LDS as unpadded 512-byte rows (what global_load_lds writes: 1 KiB = 2 rows per wave
+// instruction); bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with the row -- K: chunk ^ (row & 15)
+// (16 rows of a ds_read_b128 group hit 16 different slots), V: chunk ^ ((row & 3) << 2) (the 4 rows of a tr-read block
+// hit 4 different 64-byte bank quarters).  The swizzle is applied on the SOURCE address of the direct-to-LDS load.
+constexpr int SKS = DK;
+constexpr int SVS = DK;
 
 struct AttnArgs {
   const bf16_t* Q; long ldq;
@@ -36,7 +40,7 @@ struct AttnArgs {
   int q_tiles;
 };
 
-template <int QW, int KW>
+template <int QW, int KW, bool QMASK>
 __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int NT = 64 * QW * KW;
   constexpr int BN = 32 * KW;                       // keys per tile
@@ -62,8 +66,17 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   const int r32 = lane & 31, h = lane >> 5;
   const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
-  // blockIdx.x = bh * q_tiles + q_tile : all q-tiles of one (b, head) are adjacent so they share K/V in L2.
-  const int bh = blockIdx.x / p.q_tiles, qt = blockIdx.x % p.q_tiles;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the q-tiles of one (b, head)
+  // -- which stream the same K/V -- are given block ids that differ by multiples of 8 and thus share an L2.
+  int bh, qt;
+  if ((p.B * p.H) % 8 == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bh = xcd + 8 * (idx / p.q_tiles);
+    qt = idx % p.q_tiles;
+  } else {
+    bh = blockIdx.x / p.q_tiles;
+    qt = blockIdx.x % p.q_tiles;
+  }
   const int b = bh / p.H, hd = bh % p.H;
   const int q_row = qt * (32 * QW) + qi * 32 + r32;       // this lane's query row
   const bool q_ok = q_row < p.Sq;
@@ -71,15 +84,16 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   const bf16_t* __restrict__ Kg = p.K + (long)b * p.Sk * p.ldk + hd * DK;
   const bf16_t* __restrict__ Vg = p.V + (long)b * p.Sk * p.ldv + hd * DK;
 
-  const bool key_mask = p.mask == nullptr || p.mask_sq == 0;    // same mask for every query row -> LDS coefficients
+  constexpr bool key_mask = !QMASK;    // same mask for every query row (or none) -> LDS coefficients
   const int padded = ((p.Sk + BN - 1) / BN) * BN;
   for (int i = tid; i < padded; i += NT) {
     const bool in = i < p.Sk;
-    const bool keep = in && (!key_mask || p.mask == nullptr || p.mask[(long)b * p.mask_sb + i] != 0);
+    bool keep = in;
+    if constexpr (key_mask) keep = in && (p.mask == nullptr || p.mask[(long)b * p.mask_sb + i] != 0);
     s_coef[i] = (in && (keep || !key_mask)) ? p.scale * LOG2E : 0.f;
     s_pen[i] = in ? ((keep || !key_mask) ? 0.f : NEG_MASK * LOG2E) : -INFINITY;
   }
-  const uint8_t* __restrict__ mrow = (!key_mask) ? p.mask + (long)b * p.mask_sb + (long)(q_ok ? q_row : 0) * p.mask_sq : nullptr;
+  const uint8_t* __restrict__ mrow = QMASK ? p.mask + (long)b * p.mask_sb + (long)(q_ok ? q_row : 0) * p.mask_sq : nullptr;
 
   // Q^T fragments: lane (q = r32, h) holds Q[q][16*step + 8h .. +8)
   bf16x8 qf[DK / 16];
@@ -89,40 +103,40 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     for (int s = 0; s < DK / 16; ++s) qf[s] = q_ok ? *reinterpret_cast<const bf16x8*>(qp + 16 * s) : zero_bf16x8();
   }
 
-  // K/V staging: constant per-chunk offsets from a uniform tile base (no per-tile address arithmetic); only the
-  // last, ragged tile clamps its rows (keys past Sk get pen = -inf, so P is exactly 0 there and the clamped, finite
-  // V rows contribute nothing).
-  bf16x8 rk[CH], rv[CH];
-  static_assert(NT % (DK / 8) == 0, "a thread keeps its column; rows advance by NT / (DK/8) per chunk");
-  constexpr int RSTEP = NT / (DK / 8);                       // rows between consecutive chunks of one thread
-  const int row0 = tid / (DK / 8), col8 = (tid % (DK / 8)) * 8;
-  const int koff0 = row0 * (int)p.ldk + col8, voff0 = row0 * (int)p.ldv + col8;
-  const int lk0 = row0 * SKS + col8, lv0 = row0 * SVS + col8;
-  auto load_tile = [&](int k0) {
-    const bf16_t* Kt = Kg + (long)k0 * p.ldk;
-    const bf16_t* Vt = Vg + (long)k0 * p.ldv;
-    if (k0 + BN <= p.Sk) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        rk[i] = *reinterpret_cast<const bf16x8*>(Kt + (long)i * RSTEP * p.ldk + koff0);
-        rv[i] = *reinterpret_cast<const bf16x8*>(Vt + (long)i * RSTEP * p.ldv + voff0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int r = min(k0 + row0 + i * RSTEP, p.Sk - 1);   // clamp to the last key row
-        rk[i] = *reinterpret_cast<const bf16x8*>(Kg + (long)r * p.ldk + col8);
-        rv[i] = *reinterpret_cast<const bf16x8*>(Vg + (long)r * p.ldv + col8);
-      }
-    }
+  // K/V staging: direct-to-LDS loads (no staging registers, no ds_write).  Wave w fills tile rows [16w, 16w+16) of
+  // both operands, two rows (1 KiB) per instruction: lane l writes chunk (l & 31) of row 16w + 2i + (l >> 5) and
+  // therefore fetches the swizzled source chunk of that row.
+  constexpr int NW = QW * KW;
+  constexpr int GL = BN / 2 / NW;                      // glds instructions per operand per wave per tile
+  static_assert(BN % (2 * NW) == 0 && (BN / NW) % 16 == 0, "a wave fills whole groups of 16 rows");
+  const int hi = lane >> 5, pch = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: tile row bases become scalar
+  auto glds16 = [](const bf16_t* src, bf16_t* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  auto store_tile = [&](int buf) {
+  auto issue_tile = [&](int k0, int buf) {
     bf16_t* sK = smem + buf * STAGE;
     bf16_t* sV = sK + K_ELEMS;
+    const int wrow = wave_s * (BN / NW);
+    if (k0 + BN <= p.Sk) {
+      const bf16_t* Kt = Kg + (long)(k0 + wrow) * p.ldk;      // uniform
+      const bf16_t* Vt = Vg + (long)(k0 + wrow) * p.ldv;
+      const int klane = hi * (int)p.ldk, vlane = hi * (int)p.ldv;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      *reinterpret_cast<bf16x8*>(sK + lk0 + i * RSTEP * SKS) = rk[i];
-      *reinterpret_cast<bf16x8*>(sV + lv0 + i * RSTEP * SVS) = rv[i];
+      for (int i = 0; i < GL; ++i) {
+        const int r = 2 * i + hi;                      // row inside the wave's group (== row & 15, == row & 3 mod 4)
+        glds16(Kt + (long)(2 * i) * p.ldk + (klane + ((pch ^ (r & 15)) << 3)), sK + (wrow + 2 * i) * DK);
+        glds16(Vt + (long)(2 * i) * p.ldv + (vlane + ((pch ^ ((r & 3) << 2)) << 3)), sV + (wrow + 2 * i) * DK);
+      }
+    } else {   // ragged last tile: clamp the key row (its score gets pen = -inf, so P is exactly 0 there)
+#pragma unroll
+      for (int i = 0; i < GL; ++i) {
+        const int r = 2 * i + hi;
+        const long gr = min(k0 + wrow + r, p.Sk - 1);
+        glds16(Kg + gr * p.ldk + ((pch ^ (r & 15)) << 3), sK + (wrow + 2 * i) * DK);
+        glds16(Vg + gr * p.ldv + ((pch ^ ((r & 3) << 2)) << 3), sV + (wrow + 2 * i) * DK);
+      }
     }
   };
 
@@ -134,14 +148,18 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   float m_run = -INFINITY, l_run = 0.f;   // log2-domain running max (possibly stale by < RESCALE_THR) and sum
 
   const int nt = (p.Sk + BN - 1) / BN;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  issue_tile(0, 0);
+  __syncthreads();   // (waits for the direct-to-LDS loads: they count on vmcnt)
+
+  // swizzled fragment addressing (per-lane constants)
+  const int kx = r32 & 15;                              // K: chunk ^= row & 15 ; logical chunk of step st is 2 st + h
+  const int k_xs = kx >> 1, k_lo = ((h ^ (kx & 1)) << 3) + (32 * ki + r32) * DK;
+  const int v_lo = (32 * ki + 4 * h + q4) * DK + ((2 * g1 + (p4 >> 1)) << 3) + ((p4 & 1) << 2);   // V: chunk ^= (row & 3) << 2
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     const int k0 = t * BN;
-    if (t + 1 < nt) load_tile(k0 + BN);
+    if (t + 1 < nt) issue_tile(k0 + BN, cur ^ 1);
     const bf16_t* sK = smem + cur * STAGE;
     const bf16_t* sV = sK + K_ELEMS;
 
@@ -149,11 +167,13 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    const bf16_t* kbase = sK + (32 * ki + r32) * SKS + 8 * h;
+    const bf16_t* kbase = sK + k_lo;
+    {   // all 16 K fragments are requested before the MFMA chain starts, so LDS latency is paid once per tile
+      bf16x8 kf[DK / 16];
 #pragma unroll
-    for (int st = 0; st < DK / 16; ++st) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + 16 * st);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+      for (int st = 0; st < DK / 16; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(kbase + ((st ^ k_xs) << 4));
+#pragma unroll
+      for (int st = 0; st < DK / 16; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
     }
 
     // ---- log2-domain scores: one FMA per element with the per-key coefficient / penalty (4 consecutive keys per
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v = fmaf(s[4 * g + j], cf[j], pn[j]);
-        if (mrow) {   // per-query mask (not the encoder's case): exact masked_fill semantics from global memory
+        if constexpr (QMASK) {   // per-query mask (not the encoder's case): exact masked_fill semantics
           const int key = key0 + 8 * g + j;
           if (key < p.Sk && !mrow[key]) v = NEG_MASK * LOG2E;
         }
@@ -183,10 +203,17 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
       if (t > 0) {
+        // O^T lives in the accumulator file (MFMA C/D).  The rescale is rare; it is written with AGPR-constrained
+        // asm so the compiler keeps the 128 accumulators there instead of copying them to VGPRs on every tile.
 #pragma unroll
         for (int d = 0; d < DK / 32; ++d)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+          for (int r = 0; r < 16; ++r) {
+            float tmp;
+            asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %2, %1\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
+                         : "+a"(o[d][r]), "=&v"(tmp) : "v"(alpha));
+          }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
       }
       m_run = m_new;
     }
@@ -208,19 +235,27 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     }
 
     // ---- O^T += V^T . P^T ; V^T fragments come transposed out of the row-major V tile
-    const bf16_t* vbase = sV + (32 * ki + 4 * h + q4) * SVS + 16 * g1 + 4 * p4;
+    const bf16_t* vbase = sV + v_lo;
 #pragma unroll
-    for (int d = 0; d < DK / 32; ++d) {
+    for (int dh = 0; dh < DK / 32; dh += 4) {   // V^T fragments of four d-tiles are requested ahead of their 8 MFMAs
+      bf16x8 vf[4][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16_t* vp = vbase + (16 * ks) * SVS + 32 * d;
-        const bf16x8 vf = join8(lds_read_tr4(vp), lds_read_tr4(vp + 8 * SVS));
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
+      for (int dd = 0; dd < 4; ++dd) {
+        const bf16_t* vd = vbase + (((dh + dd) ^ q4) << 5);   // physical chunk 4 (d ^ (row & 3)) + ...
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16_t* vp = vd + (16 * ks) * SVS;
+          vf[dd][ks] = join8(lds_read_tr4(vp), lds_read_tr4(vp + 8 * SVS));
+        }
       }
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          o[dh + dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd][ks], pf[ks], o[dh + dd], 0, 0, 0);
     }
 
-    if (t + 1 < nt) store_tile(cur ^ 1);
-    __syncthreads();
+    __syncthreads();   // everyone is done with buffer `cur`, and the loads into the other buffer have landed
   }
 
   // ---- merge the KW partial states of each query block (ki > 0 publish through LDS, ki == 0 combines)
@@ -349,7 +384,8 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
   constexpr int QW = 2, KW = 2;
   a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
   dim3 grid((unsigned)(B * H * a.q_tiles)), block(64 * QW * KW);
-  hipLaunchKernelGGL((attn_fwd_kernel<QW, KW>), grid, block, 0, (hipStream_t)stream, a);
+  if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<QW, KW, true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<QW, KW, false>), grid, block, 0, (hipStream_t)stream, a);
   return hip_status(hipGetLastError());
 }
 
