@@ -15,6 +15,8 @@
 // (32 KW)-key tile; waves with the same qi keep private online-softmax state and are merged once at the end through
 // LDS.  QW=2,KW=2 gives 64-row blocks (B*H*Sq/64 >= 256 blocks at the reference shapes) with 4 MFMA-busy SIMDs per
 // CU; K/V tiles are staged global -> registers -> LDS one tile ahead (two LDS buffers, one barrier per tile).
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/bmhrl_hip.h"
 
@@ -37,7 +39,7 @@ struct AttnArgs {
   const uint8_t* mask; long mask_sb, mask_sq;
   int B, H, Sq, Sk;
   float scale, dropout_p; uint64_t seed; const uint64_t* seed_dev;
-  int q_tiles;
+  int q_tiles, dbg;
 };
 
 template <int QW, int KW, bool QMASK>
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     const int k0 = t * BN;
-    if (t + 1 < nt) issue_tile(k0 + BN, cur ^ 1);
+    if (t + 1 < nt && p.dbg != 1) issue_tile(k0 + BN, cur ^ 1);
     const bf16_t* sK = smem + cur * STAGE;
     const bf16_t* sV = sK + K_ELEMS;
 
@@ -383,6 +385,7 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev;
   constexpr int QW = 2, KW = 2;
   a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
+  a.dbg = getenv("BMHRL_ATTN_DBG") ? atoi(getenv("BMHRL_ATTN_DBG")) : 0;
   dim3 grid((unsigned)(B * H * a.q_tiles)), block(64 * QW * KW);
   if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<QW, KW, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<QW, KW, false>), grid, block, 0, (hipStream_t)stream, a);

@@ -1,0 +1,109 @@
+"""CPU tests of the host-side logic around the HIP path (no kernels are launched)."""
+import numpy as np
+import torch
+
+from bmhrl_amd import synthetic as syn
+
+
+def test_state_dict_layout_matches_reference(golden):
+    from bmhrl_amd.model.bm_hrl_agent import agent_state_shapes
+    g = golden("agent_tiny")
+    ref = {k: eval(s) for k, s in zip(g["state_keys"].tolist(), g["state_shapes"].tolist())}
+    mine = agent_state_shapes(syn.tiny_cfg(), 50)
+    assert mine == ref and len(mine) == 307
+    full = agent_state_shapes(syn.default_cfg(), 10172)
+    assert full["bm_enc.encoder.layers.0.bi_modal_att_M1.linear_K2d.weight"] == (1024, 128)
+    assert full["bm_enc.encoder.layers.1.bi_modal_att_M2.linear_d2Q.weight"] == (128, 1024)
+    assert full["worker.core.projection.weight"] == (10172, 364)
+    assert full["worker.goal_attention.linear_Q2d.weight"] == (1024, 64)
+    # 70 322 365 parameters (+19 264 for the LinearCore that is registered twice)
+    assert sum(int(np.prod(s)) for s in full.values()) == 70322365 + 19264
+
+
+def test_masks_match_oracle():
+    from bmhrl_amd.model.masking import make_masks
+    from oracle import bmhrl_oracle as O
+    b = syn.synthetic_batch(3, 9, 11, 6, 40, seed=1, d_vid=8, d_aud=4, min_len=2)
+    trg = b["captions"][:, :-1]
+    mine = make_masks({k: b[k] for k in ("rgb", "flow", "audio")}, trg, "audio_video", 1)
+    ref = O.make_masks(b["rgb"], b["audio"], trg, 1)
+    for k in ("V_mask", "A_mask", "C_mask"):
+        assert torch.equal(mine[k].bool(), ref[k].bool()), k
+    assert not mine["V_mask"][1, 0, -1]          # padded tail rows are masked out
+
+
+def test_generate_synonyms_semantics():
+    from bmhrl_amd.epoch_loops.captioning_bmrl_loops import generate_synonyms
+    g = torch.Generator().manual_seed(0)
+    cap = torch.tensor([[2, 10, 11, 12, 3, 1, 1], [2, 20, 21, 22, 23, 24, 3], [2, 5, 6, 7, 8, 9, 10]])
+    out = generate_synonyms(cap.repeat(400, 1), 50, p=0.3, generator=g).view(400, 3, 7)
+    assert (out[:, 0, 4] == 1).all() and (out[:, 1, 6] == 1).all()          # first </s> becomes pad
+    assert (out[:, 0, 5:] == 1).all()                                        # nothing after it is touched
+    changed = (out[:, 2, :] != cap[2]).float().mean()
+    assert 0.2 < float(changed) < 0.34                                       # 30 % hit, of which 90 % change the token
+    to_pad = ((out[:, 2, :] == 1) & (cap[2] != 1)).float().mean()
+    assert 0.18 < float(to_pad) < 0.30                                       # 80 % of the hits -> pad id
+
+
+def test_flat_adam_cpu_matches_torch_and_bucket_contents():
+    from bmhrl_amd.train import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=0.1)
+    opt = FlatAdam(ps, lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        for p, r in zip(ps, ref):
+            g = torch.randn_like(p)
+            p.grad = g.clone() if not (step == 1 and p.dim() == 1) else None     # one missing gradient
+            r.grad = g.clone() if p.grad is not None else torch.zeros_like(r)
+        opt.gather_grads(); opt.step()
+        opt_ref.step()
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, atol=1e-6), (p - r).abs().max()
+        assert p.data_ptr() >= opt.flat.data_ptr()                              # parameters live in the flat bucket
+
+
+def test_trainable_bucket_excludes_unreachable_parameters():
+    from types import SimpleNamespace
+    from bmhrl_amd.model.bm_hrl_agent import BMHrlAgent
+    from bmhrl_amd.train import trainable_bucket
+    cfg = syn.tiny_cfg(); cfg.device = "cpu"
+    agent = BMHrlAgent(cfg, SimpleNamespace(trg_voc_size=30, train_vocab=SimpleNamespace(vectors=None)))
+    names = {id(p): n for n, p in agent.named_parameters()}
+    got = {names[id(p)] for p in trainable_bucket(agent)}
+    assert not any(n.startswith(("critic.", "manager_core.")) or ".feed_forward.fc" in n and "_fus." in n for n in got)
+    assert "bm_enc.encoder.layers.0.feed_forward_M1.fc1.weight" in got and "emb_C.embedder.weight" in got
+    # every parameter the reference's warmstart loss reaches is in the bucket (fixture: gradients produced by the reference)
+    agent.teach_worker()
+    got_w = {names[id(p)] for p in trainable_bucket(agent)}
+    assert "manager.linear.weight" not in got_w and "worker.core.projection.weight" in got_w
+
+
+def test_install_aliases_reference_paths():
+    import importlib
+    import sys
+    import bmhrl_amd.install as inst
+    inst.install()
+    assert sys.modules["model.bm_hrl_agent"].BMHrlAgent.__module__ == "bmhrl_amd.model.bm_hrl_agent"
+    loops = importlib.import_module("epoch_loops.captioning_bmrl_loops")
+    for name in ("bimodal_decoder", "audio_decoder", "video_decoder", "bmhrl_validation_next_word_loop", "train_bmhrl_bl",
+                 "warmstart_bmhrl_bl", "train_audio_bl", "train_video_bl", "warmstart_audio_bl", "warmstart_video_bl",
+                 "analyze_bmhrl_div", "train_detr_rl", "reinforce_detr_rl", "detr_decoder"):
+        assert hasattr(loops, name), name
+
+
+def test_agent_refuses_cpu_inputs():
+    """The product has no CPU path: a forward on CPU tensors must fail loudly, not fall back."""
+    import pytest
+    from types import SimpleNamespace
+    from bmhrl_amd.model.bm_hrl_agent import BMHrlAgent
+    from bmhrl_amd.model.masking import make_masks
+    cfg = syn.tiny_cfg(); cfg.device = "cpu"
+    agent = BMHrlAgent(cfg, SimpleNamespace(trg_voc_size=30, train_vocab=SimpleNamespace(vectors=None))).eval()
+    agent.set_inference_mode(True)
+    b = syn.synthetic_batch(2, 5, 6, 4, 30, seed=0, d_vid=cfg.d_vid, d_aud=cfg.d_aud, min_len=2)
+    trg = b["captions"][:, :-1]
+    masks = make_masks({k: b[k] for k in ("rgb", "flow", "audio")}, trg, "audio_video", 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        agent((b["rgb"] + b["flow"], b["audio"]), trg, masks)
