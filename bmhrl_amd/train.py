@@ -170,7 +170,7 @@ class CaptionTrainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):
+            for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._graph_body_a()
                 self._graph_body_b(1.0)
         torch.cuda.current_stream().wait_stream(s)
