@@ -81,8 +81,15 @@ def cpu_baseline(args):
     from bmhrl_amd import synthetic as syn
     from bmhrl_amd.model.bm_hrl_agent import agent_state_shapes
     from oracle import bmhrl_oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a share of 16 host CPUs (cgroup quota, not visible in os.cpu_count()): more threads
+    # than that only oversubscribe the quota
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle step on {cores} host threads ...", file=sys.stderr, flush=True)
     cfg = syn.default_cfg(dout_p=0.0, rl_att_layers=args.layers)
     Bc = max(2, min(args.cpu_batch, args.batch))
     sd = syn.fill_state_dict(agent_state_shapes(cfg, args.vocab, with_critic=False), seed=0, clone_layers=True)
@@ -104,6 +111,7 @@ def cpu_baseline(args):
         opt.step()
 
     one()
+    print("[bench] cpu_baseline: warm-up done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     n = 2
     for _ in range(n):
