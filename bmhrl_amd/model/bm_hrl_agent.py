@@ -319,6 +319,15 @@ class BMHrlAgent(nn.Module):
     def warmstart(self, x, trg, mask):
         return self.prediction(x, trg, mask)
 
+    critic_side_stream = True
+
+    def _side_stream(self, device):
+        st = getattr(self, "_critic_stream", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_critic_stream", st)
+        return st
+
     def _segment_labels(self, emb):
         seg = torch.sigmoid(self.critic(emb))
         return (seg > self.critic_score_threshhold).squeeze().int()
@@ -341,12 +350,25 @@ class BMHrlAgent(nn.Module):
         return self.predict_with_features(emb, V, A, mask, C)
 
     def predict_with_features(self, C_emb, V, A, mask, C=None):
-        segment_labels = self._segment_labels(C_emb)
+        # The frozen critic only feeds the segment labels the manager needs at the very end: it runs on a side HIP
+        # stream (a parallel branch of the captured graph) next to the encoder / fusion kernels.
+        side = None
+        if C_emb.is_cuda and self.critic_side_stream:
+            main = torch.cuda.current_stream()
+            side = self._side_stream(C_emb.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                segment_labels = self._segment_labels(C_emb)
+            C_emb.record_stream(side)
+        else:
+            segment_labels = self._segment_labels(C_emb)
         if C is None:
             C = self.pos_enc_C(C_emb)
         Va, Av = self.bm_enc((V, A), mask)          # Va: video stream (B,Tv,d_vid), Av: audio stream (B,Ta,d_aud)
         worker_feat = self.bm_worker_fus((C, (Av, Va)), mask)
         manager_feat = self.bm_manager_fus((C, (Av, Va)), mask)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         goals = self.manager(manager_feat, segment_labels)
         pred = self.worker(worker_feat, goals, mask["C_mask"])
         return pred, worker_feat, manager_feat, goals, segment_labels
