@@ -39,6 +39,7 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.  Each wave walks `rows_per_wave` rows and keeps
 // its lanes' dgamma/dbeta partial sums in registers (<= 16 columns per lane, D <= 1024), then one atomic per column.
 constexpr int LN_MAXC = 16;
+template <int NC>
 __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
                               const float* __restrict__ dx_add, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D,
@@ -46,40 +47,43 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   const long r0 = wave_id * rows_per_wave;
-  float dg[LN_MAXC], db[LN_MAXC];
+  float dg[NC], db[NC], xv[NC], gv[NC];   // NC = ceil(D / 64): columns per lane, row cached in registers
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) dg[i] = db[i] = 0.f;
+  for (int i = 0; i < NC; ++i) dg[i] = db[i] = 0.f;
   for (long row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
     const float mu = mean[row], rs = rstd[row];
     const float* xr = x + row * D;
     const float* dyr = dy + row * D;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
+      xv[i] = gv[i] = 0.f;
       if (c < D) {
-        const float xh = (xr[c] - mu) * rs, g = dyr[c] * gamma[c];
+        const float d = dyr[c];
+        const float xh = (xr[c] - mu) * rs, g = d * gamma[c];
+        xv[i] = xh;
+        gv[i] = g;
         s1 += g;
         s2 += g * xh;
-        dg[i] += dyr[c] * xh;
-        db[i] += dyr[c];
+        dg[i] += d * xh;
+        db[i] += d;
       }
     }
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < D) {
-        const float xh = (xr[c] - mu) * rs, g = dyr[c] * gamma[c];
-        const float v = rs * (g - s1 - xh * s2);
+        const float v = rs * (gv[i] - s1 - xv[i] * s2);
         dx[row * D + c] = dx_add ? dx_add[row * D + c] + v : v;
       }
     }
   }
   // block-level reduction of the 4 waves' partial sums, then ONE atomic per column per block (per-row or per-wave
   // atomics onto the same D addresses serialise: 14x slower, MI355X_MICROARCH 'Global float atomics')
-  __shared__ float red[ROWS_PER_BLOCK][64 * LN_MAXC];
+  __shared__ float red[ROWS_PER_BLOCK][64 * NC];
   const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -87,7 +91,7 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
     if (!out) continue;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < D) red[w][c] = pass == 0 ? dg[i] : db[i];
     }
@@ -160,19 +164,31 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* 
   }
 }
 
-// db[n] (+)= sum_m dY[m][n]: block = 256 threads = 64 columns x 4 row groups, grid.y splits the rows.
+// db[n] (+)= sum_m dY[m][n]: a block covers 512 columns x `rows_per_block` rows; thread = (column group of 8 bf16 =
+// one 16-byte load, row lane 0..3); grid.y splits the rows; one atomic per column per block.
 __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ld, float* __restrict__ db, long rows, int cols,
                                    int rows_per_block) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+  __shared__ float red[4][512];
+  const int cg = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 512 + cg * 8;
   const long r0 = (long)blockIdx.y * rows_per_block;
-  float acc = 0.f;
-  if (col < cols)
-    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += 4) acc += (float)dY[r * ld + col];
-  red[ry][cx] = acc;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (col < cols) {   // ld is a multiple of 8, so the whole 8-wide group is inside the (padded) row
+    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dY + r * ld + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ry][cg * 8 + j] = acc[j];
   __syncthreads();
-  if (ry == 0 && col < cols) atomicAdd(db + col, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int gc = blockIdx.x * 512 + c;
+    if (gc < cols) atomicAdd(db + gc, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ fusion gate
@@ -301,8 +317,11 @@ extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float*
   if (rpw > 32) rpw = 32;
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-  hipLaunchKernelGGL(ln_bwd_kernel, grid, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta,
-                     (long)rows, D, rpw);
+  const int nc = (D + 63) / 64;
+#define LN_BWD(NC_) hipLaunchKernelGGL(ln_bwd_kernel<NC_>, grid, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, dx_add, \
+                                       dgamma, dbeta, (long)rows, D, rpw)
+  if (nc <= 1) LN_BWD(1); else if (nc <= 2) LN_BWD(2); else if (nc <= 5) LN_BWD(5); else if (nc <= 8) LN_BWD(8); else LN_BWD(16);
+#undef LN_BWD
   return hip_status(hipGetLastError());
 }
 
@@ -350,8 +369,11 @@ extern "C" int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t 
     hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * cols, S_(stream));
     if (e != hipSuccess) return (int)e;
   }
-  const int rpb = 128;
-  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  BMHRL_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)dY & 15) == 0);
+  const int col_blocks = (cols + 511) / 512;
+  int rpb = (int)((rows * col_blocks + 511) / 512);      // aim at ~512 blocks in total
+  if (rpb < 16) rpb = 16;
+  dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), block(256);
   hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows, cols, rpb);
   return hip_status(hipGetLastError());
 }
