@@ -69,8 +69,14 @@ def attention_roofline(dev, B, H, Sq, Sk, iters=50):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 4.0 * B * Sq * Sk * D
+    traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
+    tj = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+    if os.path.exists(tj):
+        t = json.load(open(tj))
+        if t["shape"] == {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}:
+            traffic = t["traffic_bytes_per_launch"]
     return {"bound": "mfma", "kernel": "attn_fwd_kernel<2,2> (cross-modal V<-A)", "achieved": flops / sec / 1e12,
-            "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0, "traffic": None,
+            "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0, "traffic": traffic,
             "launch_us": sec * 1e6, "flops_per_launch": flops,
             "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}}
 
