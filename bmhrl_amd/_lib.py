@@ -55,7 +55,8 @@ PROTOTYPES = {
     "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
     "bmhrl_log_softmax_bwd": [ptr, ptr, i64, ptr, i64, i64, i32, ptr],
     "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr],
-    "bmhrl_reinforce_fwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_reinforce_fwd": [ptr, i64, i32, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_reinforce_bwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
 }
 

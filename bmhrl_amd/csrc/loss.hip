@@ -199,15 +199,35 @@ __global__ void sample_kernel(const float* __restrict__ logp, long ld, int64_t* 
   }
 }
 
-__global__ void reinforce_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ action,
+__global__ void reinforce_kernel(const float* __restrict__ pred, long ld, int is_logp, const int64_t* __restrict__ action,
                                  const float* __restrict__ value, const float* __restrict__ critic_value,
                                  float* __restrict__ row_policy, float* __restrict__ row_value, long rows) {
   const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
-  const float pa = fminf(fmaxf(__expf(logp[row * ld + action[row]]), 1e-5f), 1.f - 1e-5f);
+  const float raw = pred[row * ld + action[row]];
+  const float pa = fminf(fmaxf(is_logp ? __expf(raw) : raw, 1e-5f), 1.f - 1e-5f);
   const float adv = value[row] - critic_value[row];
   row_policy[row] = -adv * __logf(pa);
   row_value[row] = adv * adv;
+}
+
+// d(mean(row_policy) + mean(row_value)) * gscale: the probability gradient has one non-zero per row (the clamp passes
+// gradient on the closed interval, like torch.clamp); value / critic gradients are +-2 adv / rows.
+__global__ void reinforce_bwd_kernel(const float* __restrict__ probs, long ld, const int64_t* __restrict__ action,
+                                     const float* __restrict__ value, const float* __restrict__ critic_value,
+                                     const float* __restrict__ gscale, float* __restrict__ dprobs,
+                                     float* __restrict__ dvalue, float* __restrict__ dcritic, long rows, int V) {
+  const long row = blockIdx.x;
+  const float g = gscale[0] / (float)rows;
+  const float adv = value[row] - critic_value[row];
+  const int a = (int)action[row];
+  const float pa = probs[row * ld + a];
+  const float ga = (pa >= 1e-5f && pa <= 1.f - 1e-5f) ? -adv / pa * g : 0.f;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) dprobs[row * (long)V + c] = (c == a) ? ga : 0.f;
+  if (threadIdx.x == 0) {
+    if (dvalue) dvalue[row] = 2.f * adv * g;
+    if (dcritic) dcritic[row] = -2.f * adv * g;
+  }
 }
 
 }  // namespace
@@ -258,11 +278,20 @@ extern "C" int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, 
   return hip_status(hipGetLastError());
 }
 
-extern "C" int bmhrl_reinforce_fwd(const float* logp, int64_t ld, const int64_t* action, const float* value,
+extern "C" int bmhrl_reinforce_fwd(const float* pred, int64_t ld, int32_t is_logp, const int64_t* action, const float* value,
                                    const float* critic_value, float* row_policy, float* row_value, int64_t rows, int32_t V,
                                    bmhrl_stream_t stream) {
-  BMHRL_CHECK_ARG(logp && action && value && critic_value && row_policy && row_value && rows > 0 && V > 0);
-  hipLaunchKernelGGL(reinforce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S_(stream), logp, (long)ld, action,
-                     value, critic_value, row_policy, row_value, (long)rows);
+  BMHRL_CHECK_ARG(pred && action && value && critic_value && row_policy && row_value && rows > 0 && V > 0);
+  hipLaunchKernelGGL(reinforce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, S_(stream), pred, (long)ld, is_logp,
+                     action, value, critic_value, row_policy, row_value, (long)rows);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_reinforce_bwd(const float* probs, int64_t ld, const int64_t* action, const float* value,
+                                   const float* critic_value, const float* gscale, float* dprobs, float* dvalue,
+                                   float* dcritic, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(probs && action && value && critic_value && gscale && dprobs && rows > 0 && V > 0);
+  hipLaunchKernelGGL(reinforce_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), probs, (long)ld, action, value,
+                     critic_value, gscale, dprobs, dvalue, dcritic, (long)rows, V);
   return hip_status(hipGetLastError());
 }

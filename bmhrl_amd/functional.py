@@ -643,3 +643,38 @@ class SmoothKLFn(torch.autograd.Function):
         ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, one, None, 0, g, rows, V, wrt_logits=False)
         g = g * drow.contiguous().view(rows, 1)
         return g.view(B, S, V), None, None, None, None, None, None
+
+
+class ReinforceFn(torch.autograd.Function):
+    """-mean(adv.detach * log clamp(p(a), 1e-5, 1-1e-5)) + mean(adv^2), adv = value - critic_value
+    (loss/biased_kl.py:69-81; `probs` are probabilities, as the reference passes them)."""
+
+    @staticmethod
+    def forward(ctx, probs, action, value, critic_value):
+        B, S, V = probs.shape
+        rows = B * S
+        dev = probs.device
+        probs = probs.contiguous()
+        a = action.reshape(-1).contiguous()
+        v = value.reshape(-1).float().contiguous()
+        c = critic_value.reshape(-1).float().contiguous()
+        rp = torch.empty(rows, device=dev)
+        rv = torch.empty(rows, device=dev)
+        ops.reinforce_fwd(probs, V, a, v, c, rp, rv, rows, V, is_logp=False)
+        ctx.save_for_backward(probs, a, v, c)
+        ctx.cfg = (B, S, V, value.shape, critic_value.shape)
+        return rp.mean() + rv.mean()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        B, S, V, vshape, cshape = ctx.cfg
+        probs, a, v, c = ctx.saved_tensors
+        rows = B * S
+        dev = probs.device
+        need = ctx.needs_input_grad
+        dprobs = torch.empty(B, S, V, device=dev)
+        dv = torch.empty(rows, device=dev) if need[2] else None
+        dc = torch.empty(rows, device=dev) if need[3] else None
+        ops.reinforce_bwd(probs, V, a, v, c, dloss.reshape(1).float().contiguous(), dprobs, dv, dc, rows, V)
+        return (dprobs if need[0] else None), None, (dv.view(vshape) if dv is not None else None), \
+            (dc.view(cshape) if dc is not None else None)

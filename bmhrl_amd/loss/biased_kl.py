@@ -41,14 +41,9 @@ class Reinforce(nn.Module):
 
     def __init__(self):
         super().__init__()
+        self.pad_idx = 0
         self.eps = 1e-5
 
     def forward(self, pred, action, value, critic_value):
-        B, S, V = pred.shape
-        rows = B * S
-        logp = torch.log(pred.detach().clamp_min(1e-38)).contiguous()
-        rp = torch.empty(rows, device=pred.device)
-        rv = torch.empty(rows, device=pred.device)
-        ops.reinforce_fwd(logp, V, action.reshape(-1).contiguous(), value.reshape(-1).float().contiguous(),
-                          critic_value.reshape(-1).float().contiguous(), rp, rv, rows, V)
-        return rp.mean() + rv.mean()
+        from ..functional import ReinforceFn
+        return ReinforceFn.apply(pred, action.reshape(pred.shape[0], pred.shape[1]), value, critic_value)

@@ -174,10 +174,17 @@ def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed):
                                                stream()), "bmhrl_sample_tokens")
 
 
-def reinforce_fwd(logp, ld, action, value, critic_value, row_policy, row_value, rows, V):
-    _lib.check(_lib.load().bmhrl_reinforce_fwd(logp.data_ptr(), ld, action.data_ptr(), value.data_ptr(),
+def reinforce_fwd(pred, ld, action, value, critic_value, row_policy, row_value, rows, V, is_logp=True):
+    _need_cuda(pred)
+    _lib.check(_lib.load().bmhrl_reinforce_fwd(pred.data_ptr(), ld, int(is_logp), action.data_ptr(), value.data_ptr(),
                                                critic_value.data_ptr(), row_policy.data_ptr(), row_value.data_ptr(), rows, V,
                                                stream()), "bmhrl_reinforce_fwd")
+
+
+def reinforce_bwd(probs, ld, action, value, critic_value, gscale, dprobs, dvalue, dcritic, rows, V):
+    _lib.check(_lib.load().bmhrl_reinforce_bwd(probs.data_ptr(), ld, action.data_ptr(), value.data_ptr(),
+                                               critic_value.data_ptr(), gscale.data_ptr(), dprobs.data_ptr(), _p(dvalue),
+                                               _p(dcritic), rows, V, stream()), "bmhrl_reinforce_bwd")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_dev=None):

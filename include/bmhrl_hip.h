@@ -170,10 +170,15 @@ int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, voi
  * greedy != 0 -> argmax.  epoch_loops/captioning_bmrl_loops.py:283-284 */
 int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
                         int32_t greedy, uint64_t seed, bmhrl_stream_t stream);
-/* Reinforce (loss/biased_kl.py:69-81): per-row terms of -adv*log(clamp(p(a))) and adv^2 */
-int bmhrl_reinforce_fwd(const float* logp, int64_t ld, const int64_t* action, const float* value,
+/* Reinforce (loss/biased_kl.py:69-81): per-row terms of -adv*log(clamp(p(a), 1e-5, 1-1e-5)) and adv^2, adv = value -
+ * critic_value; `pred` holds log-probs (is_logp = 1) or probabilities (0, the reference's input).  The backward
+ * writes d(gscale * (mean(policy) + mean(value terms))) w.r.t. the (rows, V) probabilities, value and critic_value. */
+int bmhrl_reinforce_fwd(const float* pred, int64_t ld, int32_t is_logp, const int64_t* action, const float* value,
                         const float* critic_value, float* row_policy, float* row_value, int64_t rows, int32_t V,
                         bmhrl_stream_t stream);
+int bmhrl_reinforce_bwd(const float* probs, int64_t ld, const int64_t* action, const float* value,
+                        const float* critic_value, const float* gscale /* device scalar */, float* dprobs, float* dvalue,
+                        float* dcritic, int64_t rows, int32_t V, bmhrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (K14): torch.optim.Adam semantics (scripts/train_rl_captioning_module.py:81-83, default

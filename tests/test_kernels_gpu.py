@@ -381,6 +381,14 @@ def test_loss_kernels_vs_oracle(dev, golden):
     rp = torch.empty(6, device=dev); rv = torch.empty(6, device=dev)
     ops.reinforce_fwd(lp4, 6, act, val, cv, rp, rv, 6, 6)
     assert abs(float(rp.mean() + rv.mean()) - float(k["a4_reinforce"])) < 1e-6
+    # module form (probabilities in, as the reference) with gradients, against the reference's values
+    from bmhrl_amd.loss.biased_kl import Reinforce
+    x = torch.from_numpy(g["logits"]).to(dev).requires_grad_(True)
+    val = score.to(dev).requires_grad_(True)
+    r = Reinforce()(torch.softmax(x, -1), sampled.to(dev), val, baseline.to(dev))
+    r.backward()
+    assert abs(float(r) - float(g["reinforce"])) < 1e-5 * max(1.0, abs(float(g["reinforce"])))
+    assert rel_err(x.grad, torch.from_numpy(g["reinforce_grad_logits"])) < 1e-5
 
 
 def test_sampling(dev):
