@@ -57,6 +57,9 @@ PROTOTYPES = {
     "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr],
     "bmhrl_reinforce_fwd": [ptr, i64, i32, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_reinforce_bwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_gemm_f32": [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, ptr],
+    "bmhrl_rnn_step": [i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr],
+    "bmhrl_critic_head": [ptr, ptr, ptr, f32, ptr, ptr, i64, i32, ptr],
     "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
 }
 

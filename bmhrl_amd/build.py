@@ -7,7 +7,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbmhrl_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "critic.hip"]
 
 
 def hipcc() -> str:

@@ -1,0 +1,175 @@
+// Frozen segment critic (SegmentCritic, model/bm_hrl_agent.py:186-215) for gfx950: LSTM(4) -> AReLU -> GRU(2) -> AReLU ->
+// Linear(600 -> 1) -> sigmoid > threshold, in fp32 (the labels are a hard threshold, so the arithmetic stays fp32:
+// input projections on the f32-input MFMA v_mfma_f32_32x32x2_f32, which is a k-ordered fmaf chain, recurrences on VALU).
+//
+// The recurrence is inherently serial in time; it is expressed as one small launch per (layer, time step) that the
+// host puts on a side stream / into the step's HIP graph.  Each launch: every block owns 4 hidden units (all their
+// gate rows of W_hh, 16 x H floats) and all batch rows; h_{t-1} and the weight rows are staged in LDS (16-byte
+// reads, the weight row is a broadcast across the 16 batch lanes); the gate pre-activations are exchanged through
+// LDS and 4 x 16 threads apply the cell equations.
+#include "common.h"
+#include "../../include/bmhrl_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ fp32 GEMM (MFMA)
+// C[M,N] = A[M,K] . W[N,K]^T + b1[N] (+ b2[N]);  one wave per 32x32 tile, 4 waves (2x2) per block; K % 4 == 0.
+// v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; a lane loads 4 consecutive k
+// of its row (16 bytes) and feeds elements {h, 2+h} to two MFMAs.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long lda, const float* __restrict__ W,
+                                                        long ldw, const float* __restrict__ b1, const float* __restrict__ b2,
+                                                        float* __restrict__ C, long ldc, int M, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+  if (m0 >= M || n0 >= N) return;
+  const float* ap = A + (long)min(m0 + r32, M - 1) * lda;
+  const float* wp = W + (long)min(n0 + r32, N - 1) * ldw;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; k += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wp + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[1] : a[0], h ? w[1] : w[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[3] : a[2], h ? w[3] : w[2], acc, 0, 0, 0);
+  }
+  const int n = n0 + r32;
+  if (n < N) {
+    const float bias = (b1 ? b1[n] : 0.f) + (b2 ? b2[n] : 0.f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < M) C[(long)m * ldc + n] = acc[r] + bias;
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float arelu_(float x, float alpha, float beta) {
+  // AReLU: relu(x) * (1 + sigmoid(beta)) - relu(-x) * clamp(alpha, .01, .99)   (model/bm_hrl_agent.py:13-23)
+  return x > 0.f ? x * (1.f + sigmoidf_(beta)) : x * fminf(fmaxf(alpha, 0.01f), 0.99f);
+}
+
+constexpr int UB = 4;          // hidden units per block
+constexpr int MAXH = 640;      // LDS rows hold up to 640 floats (H = 2 * d_model_caps = 600)
+
+// One LSTM (GATES = 4: i,f,g,o) or GRU (GATES = 3: r,z,n) time step of one layer.
+//   xproj: (B*L, GATES*H) = W_ih x + b_ih (+ b_hh for the LSTM)  row index b*L + t
+//   GRU: bhh (3H) is added to the hidden projection (the n gate needs r * (W_hn h + b_hn))
+template <int GATES>
+__global__ __launch_bounds__(256) void rnn_step_kernel(const float* __restrict__ xproj, const float* __restrict__ whh,
+                                                        const float* __restrict__ bhh, const float* __restrict__ h_prev,
+                                                        const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                        float* __restrict__ c_out, float* __restrict__ seq_out,
+                                                        const float* __restrict__ ar_alpha, const float* __restrict__ ar_beta,
+                                                        int B, int L, int H, int t) {
+  __shared__ __attribute__((aligned(16))) float sh_h[16][MAXH + 4];
+  __shared__ __attribute__((aligned(16))) float sh_w[16][MAXH + 4];
+  __shared__ float sh_g[16][17];
+  const int tid = threadIdx.x;
+  const int u0 = blockIdx.x * UB;
+  const int b0 = blockIdx.y * 16;
+  const int slot = tid >> 4, bl = tid & 15;          // gate-row slot (gate = slot / UB, unit = slot % UB), batch lane
+  const int gate = slot / UB, unit = u0 + slot % UB;
+  const bool row_ok = gate < GATES && unit < H;
+  // stage h_{t-1} of 16 batch rows and the 16 (12 for the GRU) weight rows
+  for (int i = tid; i < 16 * (H / 4); i += 256) {
+    const int r = i / (H / 4), c4 = (i % (H / 4)) * 4;
+    f32x4 hv = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+    if (b0 + r < B && t > 0) hv = *reinterpret_cast<const f32x4*>(h_prev + (long)(b0 + r) * H + c4);
+    const int g = r / UB, u = u0 + r % UB;
+    if (g < GATES && u < H) wv = *reinterpret_cast<const f32x4*>(whh + ((long)g * H + u) * H + c4);
+    *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = hv;
+    *reinterpret_cast<f32x4*>(&sh_w[r][c4]) = wv;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  if (row_ok && t > 0) {
+    for (int k = 0; k < H; k += 4) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(&sh_w[slot][k]);
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(&sh_h[bl][k]);
+      acc = fmaf(w[0], hv[0], acc); acc = fmaf(w[1], hv[1], acc); acc = fmaf(w[2], hv[2], acc); acc = fmaf(w[3], hv[3], acc);
+    }
+  }
+  if (row_ok && GATES == 3) acc += bhh[gate * H + unit];
+  sh_g[slot][bl] = acc;
+  __syncthreads();
+  if (tid < UB * 16) {
+    const int u = u0 + (tid >> 4), b = b0 + bl;
+    if (u < H && b < B) {
+      const int ul = tid >> 4;
+      const float* xp = xproj + ((long)b * L + t) * (GATES * H);
+      float hn;
+      if (GATES == 4) {
+        const float gi = sigmoidf_(xp[u] + sh_g[ul][bl]);
+        const float gf = sigmoidf_(xp[H + u] + sh_g[UB + ul][bl]);
+        const float gg = tanhf(xp[2 * H + u] + sh_g[2 * UB + ul][bl]);
+        const float go = sigmoidf_(xp[3 * H + u] + sh_g[3 * UB + ul][bl]);
+        const float c = gf * (t > 0 ? c_prev[(long)b * H + u] : 0.f) + gi * gg;
+        c_out[(long)b * H + u] = c;
+        hn = go * tanhf(c);
+      } else {
+        const float r = sigmoidf_(xp[u] + sh_g[ul][bl]);
+        const float z = sigmoidf_(xp[H + u] + sh_g[UB + ul][bl]);
+        const float n = tanhf(xp[2 * H + u] + r * sh_g[2 * UB + ul][bl]);
+        hn = (1.f - z) * n + z * (t > 0 ? sh_h[bl][u] : 0.f);
+      }
+      h_out[(long)b * H + u] = hn;
+      seq_out[((long)b * L + t) * H + u] = ar_alpha ? arelu_(hn, ar_alpha[0], ar_beta[0]) : hn;
+    }
+  }
+}
+
+// labels[row] = sigmoid(lin_w . x[row] + lin_b) > thr ; also the raw score (for tests / callers)
+__global__ void critic_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                   float thr, float* __restrict__ score, int32_t* __restrict__ labels, long rows, int H) {
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int k = lane; k < H; k += 64) acc = fmaf(x[row * H + k], w[k], acc);
+  acc = wave_sum(acc) + b[0];
+  if (lane == 0) {
+    if (score) score[row] = acc;
+    if (labels) labels[row] = sigmoidf_(acc) > thr ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int bmhrl_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias1,
+                              const float* bias2, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                              bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0);
+  BMHRL_CHECK_ARG((((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), block(256);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, S_(stream), A, (long)lda, W, (long)ldw, bias1, bias2, C, (long)ldc, M, N, K);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_rnn_step(int32_t gates, const float* xproj, const float* whh, const float* bhh, const float* h_prev,
+                              const float* c_prev, float* h_out, float* c_out, float* seq_out, const float* arelu_alpha,
+                              const float* arelu_beta, int32_t B, int32_t L, int32_t H, int32_t t, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG((gates == 3 || gates == 4) && xproj && whh && h_out && seq_out && B > 0 && L > 0 && t >= 0 && t < L);
+  BMHRL_CHECK_ARG(H > 0 && H <= MAXH && H % 4 == 0 && (t == 0 || h_prev) && (gates == 3 ? bhh != nullptr : c_out != nullptr));
+  BMHRL_CHECK_ARG((arelu_alpha == nullptr) == (arelu_beta == nullptr));
+  dim3 grid((unsigned)((H + UB - 1) / UB), (unsigned)((B + 15) / 16)), block(256);
+  if (gates == 4)
+    hipLaunchKernelGGL(rnn_step_kernel<4>, grid, block, 0, S_(stream), xproj, whh, bhh, h_prev, c_prev, h_out, c_out, seq_out,
+                       arelu_alpha, arelu_beta, B, L, H, t);
+  else
+    hipLaunchKernelGGL(rnn_step_kernel<3>, grid, block, 0, S_(stream), xproj, whh, bhh, h_prev, c_prev, h_out, c_out, seq_out,
+                       arelu_alpha, arelu_beta, B, L, H, t);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_critic_head(const float* x, const float* w, const float* b, float threshold, float* score,
+                                 int32_t* labels, int64_t rows, int32_t H, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && w && b && (score || labels) && rows > 0 && H > 0);
+  hipLaunchKernelGGL(critic_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(stream), x, w, b, threshold, score,
+                     labels, (long)rows, H);
+  return hip_status(hipGetLastError());
+}

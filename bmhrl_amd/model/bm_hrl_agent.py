@@ -141,9 +141,41 @@ class SegmentCritic(nn.Module):
 
     def forward(self, emb):
         with torch.no_grad():
-            h, _ = self.lstm(emb)
+            if emb.is_cuda:
+                return self.score_and_labels(emb, 0.0)[0]
+            h, _ = self.lstm(emb)          # host tensors (tests of the module wiring): torch's own RNN
             h, _ = self.gru(self.relu(h))
             return self.lin(self.relu2(h))
+
+    def score_and_labels(self, emb, threshold):
+        """HIP path: fp32 input projections on the f32 MFMA + one small launch per (layer, time step).
+        Returns (score (B, L, 1), labels (B, L) int32 = sigmoid(score) > threshold)."""
+        from .. import ops
+        B, L, d = emb.shape
+        dev = emb.device
+        H = self.lstm.hidden_size
+        rows = B * L
+        x = emb.detach().contiguous().view(rows, d)
+        hb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+        cb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+        for kind, rnn, gates, n_layers, act in (("lstm", self.lstm, 4, 4, self.relu), ("gru", self.gru, 3, 2, self.relu2)):
+            for l in range(n_layers):
+                w_ih, w_hh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
+                b_ih, b_hh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
+                K = x.shape[1]
+                xproj = torch.empty(rows, gates * H, device=dev)
+                ops.gemm_f32(x, w_ih, b_ih, b_hh if gates == 4 else None, xproj, rows, gates * H, K)
+                seq = torch.empty(rows, H, device=dev)
+                last = l == n_layers - 1
+                for t in range(L):
+                    ops.rnn_step(gates, xproj, w_hh, b_hh if gates == 3 else None, hb[(t + 1) & 1], cb[(t + 1) & 1], hb[t & 1],
+                                 cb[t & 1] if gates == 4 else None, seq, act.alpha if last else None,
+                                 act.beta if last else None, B, L, H, t)
+                x = seq
+        score = torch.empty(B, L, 1, device=dev)
+        labels = torch.empty(B, L, dtype=torch.int32, device=dev)
+        ops.critic_head(x, self.lin.weight, self.lin.bias, float(threshold), score, labels, rows, H)
+        return score, labels
 
 
 class LinearCore(nn.Module):
@@ -329,6 +361,10 @@ class BMHrlAgent(nn.Module):
         return st
 
     def _segment_labels(self, emb):
+        if emb.is_cuda:
+            # same values as (sigmoid(critic(C)) > thr).squeeze().int() of the reference (:638-640); the squeeze only
+            # changes the shape when B == 1 or L == 1
+            return self.critic.score_and_labels(emb, self.critic_score_threshhold)[1].squeeze()
         seg = torch.sigmoid(self.critic(emb))
         return (seg > self.critic_score_threshhold).squeeze().int()
 

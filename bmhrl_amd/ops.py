@@ -190,3 +190,20 @@ def reinforce_bwd(probs, ld, action, value, critic_value, gscale, dprobs, dvalue
 def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, step_dev=None):
     _lib.check(_lib.load().bmhrl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, lr,
                                            beta1, beta2, eps, weight_decay, step, _p(step_dev), grad_scale, stream()), "bmhrl_adam_step")
+
+
+def gemm_f32(A, W, bias1, bias2, C, M, N, K):
+    _need_cuda(A, W, C)
+    _lib.check(_lib.load().bmhrl_gemm_f32(A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), _p(bias1), _p(bias2),
+                                          C.data_ptr(), C.stride(0), M, N, K, stream()), "bmhrl_gemm_f32")
+
+
+def rnn_step(gates, xproj, whh, bhh, h_prev, c_prev, h_out, c_out, seq_out, ar_alpha, ar_beta, B, L, H, t):
+    _lib.check(_lib.load().bmhrl_rnn_step(gates, xproj.data_ptr(), whh.data_ptr(), _p(bhh), _p(h_prev), _p(c_prev),
+                                          h_out.data_ptr(), _p(c_out), seq_out.data_ptr(), _p(ar_alpha), _p(ar_beta), B, L, H, t,
+                                          stream()), "bmhrl_rnn_step")
+
+
+def critic_head(x, w, b, threshold, score, labels, rows, H):
+    _lib.check(_lib.load().bmhrl_critic_head(x.data_ptr(), w.data_ptr(), b.data_ptr(), threshold, _p(score), _p(labels), rows, H,
+                                             stream()), "bmhrl_critic_head")

@@ -181,6 +181,23 @@ int bmhrl_reinforce_bwd(const float* probs, int64_t ld, const int64_t* action, c
                         float* dcritic, int64_t rows, int32_t V, bmhrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Frozen segment critic (K15; SegmentCritic.forward, model/bm_hrl_agent.py:204-215), fp32 throughout because its
+ * output is thresholded into integer segment labels (:638-640).
+ *  bmhrl_gemm_f32   : C[M,N] = A[M,K] W[N,K]^T + bias1 + bias2 on the f32-input MFMA (input projections W_ih x + b)
+ *  bmhrl_rnn_step   : one time step of one LSTM (gates = 4, order i,f,g,o) or GRU (gates = 3, order r,z,n) layer:
+ *                     xproj (B*L, gates*H) row b*L + t, W_hh (gates*H, H), b_hh (GRU only), state ping-pong buffers
+ *                     (B, H); writes h_t (optionally through AReLU, :13-23) to seq_out (B*L, H)
+ *  bmhrl_critic_head: score = lin(x), labels = sigmoid(score) > threshold
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias1, const float* bias2,
+                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, bmhrl_stream_t stream);
+int bmhrl_rnn_step(int32_t gates, const float* xproj, const float* whh, const float* bhh, const float* h_prev,
+                   const float* c_prev, float* h_out, float* c_out, float* seq_out, const float* arelu_alpha,
+                   const float* arelu_beta, int32_t B, int32_t L, int32_t H, int32_t t, bmhrl_stream_t stream);
+int bmhrl_critic_head(const float* x, const float* w, const float* b, float threshold, float* score, int32_t* labels,
+                      int64_t rows, int32_t H, bmhrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimiser (K14): torch.optim.Adam semantics (scripts/train_rl_captioning_module.py:81-83, default
  * betas/eps, L2 weight decay added to the gradient) over one flat fp32 bucket; grad_scale multiplies
  * the gradient first (1/world for data parallel averaging).

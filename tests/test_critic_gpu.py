@@ -1,0 +1,49 @@
+"""The HIP segment critic (fp32 MFMA input projections + per-step recurrence kernels) against the fixture produced by the
+reference's SegmentCritic and against the CPU oracle at the real width (d=300, H=600, B=16, L=30)."""
+import numpy as np
+import pytest
+import torch
+
+from bmhrl_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _critic(cfg, dev):
+    from bmhrl_amd.model.bm_hrl_agent import SegmentCritic
+    c = SegmentCritic(cfg)
+    c.load_state_dict(syn.synthetic_critic_state(cfg.d_model_caps, seed=1))
+    return c.to(dev)
+
+
+def test_critic_matches_reference_fixture(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = golden("critic")
+    cfg = syn.tiny_cfg()
+    c = _critic(cfg, dev)
+    emb = torch.from_numpy(g["emb"]).to(dev)
+    score, labels = c.score_and_labels(emb, 0.25)
+    ref = torch.from_numpy(g["out"])
+    assert float((score.cpu() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(labels.cpu(), (torch.sigmoid(ref) > 0.25).squeeze(-1).int())
+    assert torch.equal(c(emb).cpu(), score.cpu())        # module call == reference forward signature
+
+
+def test_critic_full_width_vs_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import bmhrl_oracle as O
+    dev = torch.device("cuda:0")
+    cfg = syn.default_cfg()
+    c = _critic(cfg, dev)
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(16, 30, 300, generator=g) * 17.3      # embeddings are scaled by sqrt(300) in the agent
+    sd = {"critic." + k: v for k, v in syn.synthetic_critic_state(300, seed=1).items()}
+    ref = O.segment_critic(sd, "critic", emb)
+    score, labels = c.score_and_labels(emb.to(dev), 0.25)
+    assert float((score.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    margin = (ref.squeeze(-1) - float(np.log(0.25 / 0.75))).abs()
+    ok = margin > 1e-4                                      # labels must agree wherever the score is not on the threshold
+    assert torch.equal(labels.cpu()[ok], O.segment_labels(ref, 0.25)[ok])
