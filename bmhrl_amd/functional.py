@@ -326,6 +326,53 @@ class MHAFn(torch.autograd.Function):
         return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None)
 
 
+class AttnCoreFn(torch.autograd.Function):
+    """dropout( softmax(q k^T / sqrt(d_k), masked with -1e9) v ) on already projected fp32 (B,S,D) tensors, heads being
+    d_k-wide column slices -- model/multihead_attention.py:7-31.  The general entry (q, k and v from three different
+    inputs) used by the post-norm layers of model/encoder.py:59-69 and model/decoder.py:66-100; the bimodal hot path
+    goes through MHAFn, which fuses the projections around the same kernels."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, H, p_drop):
+        dev = q.device
+        B, Sq, D = q.shape
+        Sk = k.shape[1]
+        dk = D // H
+        if D % 8 or dk % 8:
+            raise ValueError("AttnCoreFn needs d_model and d_k to be multiples of 8")
+        rows_q, rows_k = B * Sq, B * Sk
+        Qb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
+        KV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
+        ops.cast_bf16(q.contiguous(), D, Qb, D, rows_q, D)
+        ops.cast_bf16(k.contiguous(), D, KV, 2 * D, rows_k, D)
+        ops.cast_bf16(v.contiguous(), D, KV, 2 * D, rows_k, D, y_off=D)
+        m8, msb, msq = _mask_u8(mask)
+        seed = SEEDS.next()
+        Ob, stats = _attn_core_fwd(Qb, 0, D, KV, 0, 2 * D, KV, D, 2 * D, m8, msb, msq, B, H, Sq, Sk, dk, p_drop, seed)
+        ctx.save_for_backward(Qb, KV, Ob, m8, *stats[1:])
+        ctx.cfg = (B, H, Sq, Sk, D, dk, p_drop, seed, stats[0], msb, msq)
+        return Ob.float().view(B, Sq, D)
+
+    @staticmethod
+    def backward(ctx, dO):
+        B, H, Sq, Sk, D, dk, p_drop, seed, kind, msb, msq = ctx.cfg
+        Qb, KV, Ob, m8 = ctx.saved_tensors[:4]
+        stats = (kind,) + tuple(ctx.saved_tensors[4:])
+        dev = dO.device
+        rows_q, rows_k = B * Sq, B * Sk
+        dOb = torch.empty(rows_q, D, dtype=_BF16, device=dev)   # gradient w.r.t. the pre-dropout output
+        ops.cast_bf16(dO.contiguous(), D, dOb, D, rows_q, D, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+        dQb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
+        dKV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
+        _attn_core_bwd(dOb, Ob, stats, Qb, 0, D, KV, 0, 2 * D, KV, D, 2 * D, dQb, 0, D, dKV, 0, 2 * D, dKV, D, 2 * D,
+                       m8, msb, msq, B, H, Sq, Sk, dk, p_drop)
+        need = ctx.needs_input_grad
+        dq = dQb.float().view(B, Sq, D) if need[0] else None
+        dk_ = dKV[:, :D].float().view(B, Sk, D) if need[1] else None
+        dv = dKV[:, D:].float().view(B, Sk, D) if need[2] else None
+        return dq, dk_, dv, None, None, None
+
+
 class FFNFn(torch.autograd.Function):
     """x + dropout( fc2( dropout( relu( fc1( LN(x) ) ) ) ) ) -- model/blocks.py:135-144 around :175-187."""
 

@@ -4,6 +4,7 @@
     import bmhrl_amd.install  # before `from model.bm_hrl_agent import BMHrlAgent`
 
 Only the hot-path modules are aliased (model.bm_hrl_agent, model.blocks, model.multihead_attention, model.masking,
+model.encoder, model.decoder, model.utils,
 loss.label_smoothing, loss.biased_kl, epoch_loops.captioning_bmrl_loops); everything else keeps resolving to the
 reference's own files."""
 import importlib
@@ -15,6 +16,9 @@ ALIASES = {
     "model.blocks": "bmhrl_amd.model.blocks",
     "model.multihead_attention": "bmhrl_amd.model.multihead_attention",
     "model.masking": "bmhrl_amd.model.masking",
+    "model.encoder": "bmhrl_amd.model.encoder",
+    "model.decoder": "bmhrl_amd.model.decoder",
+    "model.utils": "bmhrl_amd.model.utils",
     "loss.label_smoothing": "bmhrl_amd.loss.label_smoothing",
     "loss.biased_kl": "bmhrl_amd.loss.biased_kl",
     "epoch_loops.captioning_bmrl_loops": "bmhrl_amd.epoch_loops.captioning_bmrl_loops",

@@ -1,8 +1,9 @@
 """MultiheadedAttention with the reference's constructor, attributes and state-dict keys
 (model/multihead_attention.py:34-92); forward runs the fused HIP path of bmhrl_amd.functional.MHAFn."""
+import torch
 import torch.nn as nn
 
-from ..functional import MHAFn
+from ..functional import AttnCoreFn, LinearFn, MHAFn
 
 
 class MultiheadedAttention(nn.Module):
@@ -35,10 +36,18 @@ class MultiheadedAttention(nn.Module):
         return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual)
 
     def forward(self, Q, K, V, mask, causal=False):
-        """Reference signature: Q (B,Sq,Dq), K/V (B,Sk,Dk), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).
-        K and V must be the same tensor (they are at every call site of the hot path)."""
-        if causal:
-            raise NotImplementedError("causal=True is only used by the DETR decoder (out of scope, SURVEY.md section 2 #5)")
-        if K is not V:
-            raise NotImplementedError("the hot path always passes K is V")
-        return self.fused(Q, None if K is Q else K, mask)
+        """Reference signature: Q (B,Sq,Dq), K (B,Sk,Dk), V (B,Sk,Dv), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).
+        K is V (every call site of the bimodal agent) runs the fused path; distinct K and V inputs or `causal=True`
+        (the post-norm layers of model/encoder.py / model/decoder.py) run projection GEMMs + the attention core."""
+        if K is V and not causal:
+            return self.fused(Q, None if K is Q else K, mask)
+        p = self.dout_p if self.training else 0.0
+        if causal and mask is not None:
+            # model/multihead_attention.py:19-22: a lower-triangular fill (sized by the key axis) on top of the mask
+            Sk = mask.shape[-1]
+            mask = mask.bool() & torch.ones(Sk, Sk, dtype=torch.bool, device=mask.device).tril().unsqueeze(0)
+        q = LinearFn.apply(Q, self.linear_Q2d.weight, self.linear_Q2d.bias, False, 0.0)
+        k = LinearFn.apply(K, self.linear_K2d.weight, self.linear_K2d.bias, False, 0.0)
+        v = LinearFn.apply(V, self.linear_V2d.weight, self.linear_V2d.bias, False, 0.0)
+        o = AttnCoreFn.apply(q, k, v, mask, self.H, p)
+        return LinearFn.apply(o, self.linear_d2Q.weight, self.linear_d2Q.bias, False, 0.0)

@@ -144,3 +144,17 @@ def synthetic_batch(B: int, Tv: int, Ta: int, L: int, V: int, seed: int = 0, d_v
 def synthetic_rewards(B: int, L: int, seed: int = 2) -> torch.Tensor:
     g = np.random.Generator(np.random.PCG64(seed))
     return torch.from_numpy(g.random((B, L), dtype=np.float32))
+
+
+def detr_tiny_modules():
+    """The post-norm encoder / decoder stacks at the size of tests/golden/detr.npz, with the fixture's weights
+    (fill_state_dict seed 9).  Returns (encoder, decoder, dims)."""
+    import torch.nn as nn
+    from .model.decoder import TransformerDecoder, TransformerDecoderLayer
+    from .model.encoder import TransformerEncoder, TransformerEncoderLayer
+    dims = dict(B=3, S=9, L=6, D=64, dC=24, dG=8, H=4, dff=48)
+    enc = TransformerEncoder(TransformerEncoderLayer(64, 4, 48, 0.0, embed_size=20), 2, nn.LayerNorm(64))
+    dec = TransformerDecoder(TransformerDecoderLayer(64, 4, 24, 8, 48, 0.0), 2, nn.LayerNorm(24))
+    for m in (enc, dec):
+        m.load_state_dict(fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=9))
+    return enc, dec, dims

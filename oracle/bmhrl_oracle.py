@@ -428,3 +428,54 @@ def greedy_decode(sd: SD, cfg, rgb: Tensor, flow: Tensor, audio: Tensor, max_len
             trg = torch.cat([trg, nxt], dim=-1)
             done = done | (nxt == end_idx)
     return trg
+
+
+# --------------------------------------------------------------------------------------
+# post-norm (DETR-style) layers -- model/encoder.py, model/decoder.py
+# --------------------------------------------------------------------------------------
+def causal_mask(mask: Optional[Tensor], causal: bool) -> Optional[Tensor]:
+    """model/multihead_attention.py:17-22: with `causal`, logits above the diagonal are filled with -1e9 before the mask
+    is applied -- the same as masking with (mask AND lower-triangular).  Skipped when there is no mask at all (:17)."""
+    if mask is None or not causal:
+        return mask
+    S = mask.shape[-1]
+    return mask.bool() & torch.ones(S, S, dtype=torch.bool).tril().unsqueeze(0)
+
+
+def detr_encoder_layer(sd: SD, p: str, src: Tensor, mask: Optional[Tensor], H: int) -> Tensor:
+    """TransformerEncoderLayer.forward_post, model/encoder.py:59-69 (pos = PositionalEncoder, dropout off)."""
+    qk = add_posenc(src)
+    src = layer_norm(sd, p + ".norm1", src + mha(sd, p + ".self_attn", qk, qk, src, mask, H))
+    ff = linear(sd, p + ".linear2", torch.relu(linear(sd, p + ".linear1", src)))
+    return layer_norm(sd, p + ".norm2", src + ff)
+
+
+def detr_decoder_layer(sd: SD, p: str, tgt: Tensor, memory: Tensor, memory_mask, query_pos, query_mask, goal, goal_mask,
+                       add_pos: bool, detected_objects, H: int) -> Tensor:
+    """TransformerDecoderLayer.forward_post, model/decoder.py:66-100.  `query_pos` is None for "PositionalEncoder"
+    (add_pos=False, causal self attention) or a tensor added to tgt (add_pos=True).  norm1 is applied to tgt before the
+    self-attention branch is added (:77-78); `forward` always passes obj_mask=None (:106)."""
+    qk = add_posenc(tgt) if not add_pos else tgt + query_pos
+    branch = mha(sd, p + ".self_attn", qk, qk, tgt, causal_mask(query_mask, not add_pos), H)
+    tgt = layer_norm(sd, p + ".norm1", tgt) + branch
+    tgt = layer_norm(sd, p + ".norm2", tgt + mha(sd, p + ".multihead_attn", qk, add_posenc(memory), memory, memory_mask, H))
+    if goal is not None:
+        branch = mha(sd, p + ".goal_attention", add_posenc(tgt), add_posenc(goal), goal, goal_mask, H)
+        tgt = layer_norm(sd, p + ".norm4", tgt + branch)
+    if detected_objects is not None:
+        tgt = layer_norm(sd, p + ".norm5", tgt + mha(sd, p + ".detected_attention", qk, detected_objects, detected_objects, None, H))
+    ff = linear(sd, p + ".linear2", torch.relu(linear(sd, p + ".linear1", tgt)))
+    return layer_norm(sd, p + ".norm3", tgt + ff)
+
+
+def detr_stack(sd: SD, p: str, n_layers: int, x: Tensor, layer_fn, has_norm: bool, return_intermediate: bool = True) -> Tensor:
+    """TransformerEncoder.forward / TransformerDecoder.forward, model/encoder.py:20-37, model/decoder.py:17-37: with a
+    final norm the last intermediate becomes norm(norm(output)) (output is normalised, then normalised again on append)."""
+    inter = []
+    for i in range(n_layers):
+        x = layer_fn(f"{p}.layers.{i}", x)
+        inter.append(x)
+    if has_norm:
+        x = layer_norm(sd, p + ".norm", x)
+        inter[-1] = layer_norm(sd, p + ".norm", x)
+    return torch.stack(inter) if return_intermediate else x

@@ -257,6 +257,46 @@ def sample_clip_decode():
                         tokens=np_(trg), first_logp=np_(first), first_margin=np_(top2[0] - top2[1]), voc=np.array(Vsz))
 
 
+def detr_cases():
+    """Post-norm encoder / decoder stacks (model/encoder.py, model/decoder.py).  The reference's `causal=True` branch
+    builds its triangular fill on `get_device()`, which is -1 on the CPU and raises; the cases here stay on the branches
+    that run on the CPU reference: a tensor query position (add_pos=True), and add_pos=False without a query mask (the
+    causal fill is skipped when mask is None, model/multihead_attention.py:17)."""
+    from model.blocks import PositionalEncoder
+    from model.decoder import TransformerDecoder, TransformerDecoderLayer
+    from model.encoder import TransformerEncoder, TransformerEncoderLayer
+    g = torch.Generator().manual_seed(21)
+    B, S, L, D, dC, dG, H, dff = 3, 9, 6, 64, 24, 8, 4, 48
+    out = {}
+
+    def load(m):
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(syn.fill_state_dict(shapes, seed=9))
+        return m.eval()
+
+    with quiet:
+        enc = load(TransformerEncoder(TransformerEncoderLayer(D, H, dff, 0.0, embed_size=20), 2, torch.nn.LayerNorm(D)))
+        dec = load(TransformerDecoder(TransformerDecoderLayer(D, H, dC, dG, dff, 0.0), 2, torch.nn.LayerNorm(dC)))
+    src = torch.randn(B, S, D, generator=g)
+    mask = torch.ones(B, 1, S, dtype=torch.bool)
+    mask[0, 0, S - 3:] = False
+    mask[2, 0, :2] = False
+    memory = enc(src, mask, PositionalEncoder(D, 0.0))
+    out["src"], out["mask"], out["enc_out"] = np_(src), np_(mask), np_(memory)
+    tgt = torch.randn(B, L, dC, generator=g)
+    qpos = 0.3 * torch.randn(B, L, dC, generator=g)
+    qmask = torch.tril(torch.ones(B, L, L, dtype=torch.bool))
+    qmask[1, :, 4:] = False
+    objs = torch.randn(B, 5, 256, generator=g)
+    goal = torch.randn(B, L, dG, generator=g)
+    mem = memory[-1].detach()
+    a = dec(tgt, mem, mask, PositionalEncoder(D, 0.0), qpos, qmask, None, None, None, True, objs, None)
+    b = dec(tgt, mem, mask, PositionalEncoder(D, 0.0), PositionalEncoder(dC, 0.0), None, goal, qmask, PositionalEncoder(dG, 0.0),
+            False, None, None)
+    out.update(tgt=np_(tgt), qpos=np_(qpos), qmask=np_(qmask), objs=np_(objs), goal=np_(goal), dec_a=np_(a), dec_b=np_(b))
+    np.savez_compressed(os.path.join(HERE, "detr.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -266,6 +306,7 @@ if __name__ == "__main__":
     critic_case()
     agent_tiny()
     sample_clip_decode()
+    detr_cases()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -185,3 +185,23 @@ def test_sample_clip_greedy_decode(golden):
     rgb, flow, audio = T(g["rgb"]), T(g["flow"]), T(g["audio"])
     toks = O.greedy_decode(sd, cfg, rgb, flow, audio, 12, 2, 3, 1)
     assert np.array_equal(toks.numpy(), g["tokens"])
+
+
+def test_detr_layers(golden):
+    """Post-norm encoder / decoder stacks (model/encoder.py, model/decoder.py) against the reference's outputs."""
+    g = golden("detr")
+    enc, dec, d = syn.detr_tiny_modules()
+    esd = {"enc." + k: v for k, v in enc.state_dict().items()}
+    dsd = {"dec." + k: v for k, v in dec.state_dict().items()}
+    H = d["H"]
+    src, mask = T(g["src"]), T(g["mask"])
+    mem_all = O.detr_stack(esd, "enc", 2, src, lambda p, x: O.detr_encoder_layer(esd, p, x, mask, H), True)
+    close(mem_all, g["enc_out"])
+    mem = T(g["enc_out"])[-1]
+    tgt, qpos, qmask, objs, goal = (T(g[k]) for k in ("tgt", "qpos", "qmask", "objs", "goal"))
+    a = O.detr_stack(dsd, "dec", 2, tgt, lambda p, x: O.detr_decoder_layer(dsd, p, x, mem, mask, qpos, qmask, None, None,
+                                                                             True, objs, H), True)
+    close(a, g["dec_a"])
+    b = O.detr_stack(dsd, "dec", 2, tgt, lambda p, x: O.detr_decoder_layer(dsd, p, x, mem, mask, None, None, goal, qmask,
+                                                                             False, None, H), True)
+    close(b, g["dec_b"])
