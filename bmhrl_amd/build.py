@@ -8,6 +8,9 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbmhrl_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "critic.hip"]
+# attention.hip: the eight 16-register O^T accumulators are loop-carried vector PHIs; AMDGPUCodeGenPrepare would break
+# them into 128 scalar (VGPR) PHIs, i.e. 128 accumulator<->VGPR copies per key tile around the MFMAs.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]}
 
 
 def hipcc() -> str:
@@ -34,7 +37,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c",
-               os.path.join(CSRC, s), "-o", o]
+               os.path.join(CSRC, s), "-o", o] + EXTRA_FLAGS.get(s, [])
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, cwd=CSRC)))

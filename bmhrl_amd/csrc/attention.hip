@@ -4,18 +4,38 @@
 // self- and cross-modal attentions of BMEncoderLayer and the caption->memory attentions of BMFusionLayer.
 //
 // Formulation (everything transposed so that a query row lives on ONE lane):
-//   S^T (keys x q)  = K_tile . Q^T          A = K rows from LDS (ds_read_b128), B = Q^T fragments held in registers
+//   S^T (keys x q)  = K_tile . Q^T          A = K rows, B = Q^T fragments held in registers
 //   softmax over keys = over the 16 accumulator registers of a lane + one lane^32 exchange (no LDS, no permute)
 //   O^T (d x q)    += V^T . P^T             A = V^T read from the row-major V tile by ds_read_b64_tr_b16,
 //                                           B = the S^T accumulator converted to bf16 in place (k order of the
 //                                           accumulator: key = 16s + 8(j>>2) + 4h + (j&3))
 // so the running max / sum / rescale factors are per-lane scalars and O^T rescaling needs no cross-lane traffic.
 //
-// Work split: block = QW x KW waves.  Wave (qi, ki) owns 32 query rows and the keys [32 ki, 32 ki + 32) of every
-// (32 KW)-key tile; waves with the same qi keep private online-softmax state and are merged once at the end through
-// LDS.  QW=2,KW=2 gives 64-row blocks (B*H*Sq/64 >= 256 blocks at the reference shapes) with 4 MFMA-busy SIMDs per
-// CU; K/V tiles are staged global -> registers -> LDS one tile ahead (two LDS buffers, one barrier per tile).
+// Work split: block = 2 x 2 waves, 64 query rows (B*H*Sq/64 >= 256 blocks at the reference shapes, one wave per SIMD).
+// Wave (qi, ki) owns 32 query rows and the keys [32 ki, 32 ki + 32) of every 64-key tile; the two key halves keep
+// private online-softmax state and are merged once at the end through LDS.
+//
+// Data movement and schedule:
+//   * K and V tiles go global -> LDS with direct-to-LDS loads (no staging registers, no ds_write), two stages each,
+//     issued at the top of an iteration for the next one; rows are XOR-swizzled (on the source address) so that the
+//     ds_read_b128 of K and the transposed reads of V are bank-conflict free without padding;
+//   * the loop is software pipelined inside the single wave a SIMD holds: the S^T MFMA chain of tile t+1 carries one
+//     exponential of tile t under every MFMA, the O^T MFMAs of tile t carry the score scaling / row max of tile t+1;
+//   * tiles whose keys are all valid and unmasked (nearly all) scale scores by one constant; the per-key coefficient
+//     path (mask, padding, per-query masks) is a rare wave-uniform fix-up;
+//   * LDS reads inside the loop are inline asm with hand-counted lgkmcnt waits: the compiler orders every ds_read it
+//     knows about behind ALL outstanding direct-to-LDS loads (it cannot tell the stages apart, so each became a
+//     vmcnt(0) that serialised the prefetch);
+//   * Q fragments are pinned to the accumulator half of the register file (MFMA reads B operands from there), the
+//     O^T accumulators are handed to the rare rescale as whole 16-register tuples, and the file is built with
+//     -amdgpu-codegenprepare-break-large-phis=false: otherwise the loop-carried accumulators are split into 128 scalar
+//     VGPR PHIs, i.e. 256 accumulator<->VGPR copies per tile.
+// Bounds at the reference shape (64 query rows per CU): per 64-key tile a CU needs 1024 MFMA cycles per SIMD, 128 KiB
+// of LDS reads (1024 cycles at 128 B/clk) and 64 KiB through the vector memory path (1024 cycles at 64 B/clk) -- the
+// three pipes are balanced, so the kernel is as much LDS/L1-bandwidth bound as MFMA bound.  (Loading K fragments
+// straight from global memory was tried: 32 rows x 32 bytes per load instruction makes it TCP-line-rate bound, slower.)
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "../../include/bmhrl_hip.h"
@@ -23,12 +43,16 @@
 namespace {
 
 constexpr int DK = 256;
-// K / V tiles sit in LDS as unpadded 512-byte rows (what global_load_lds writes: 1 KiB = 2 rows per wave
-// instruction); bank conflicts are avoided by XOR-swizzling the 16-byte chunk index with the row -- K: chunk ^ (row & 15)
-// (16 rows of a ds_read_b128 group hit 16 different slots), V: chunk ^ ((row & 3) << 2) (the 4 rows of a tr-read block
-// hit 4 different 64-byte bank quarters).  The swizzle is applied on the SOURCE address of the direct-to-LDS load.
-constexpr int SKS = DK;
-constexpr int SVS = DK;
+constexpr int QW = 2, KW = 2, NT = 64 * QW * KW;
+constexpr int BN = 32 * KW;                 // keys per tile
+constexpr int VST = BN * DK;                // elements of one K or V stage (32 KiB)
+constexpr int LDS_KV = 4 * VST * 2;         // bytes: K stage 0, K stage 1, V stage 0, V stage 1
+// per-key softmax coefficients of one batch row: score2 = fma(q.k, coef[key], pen[key]) in the log2 domain
+//   valid key  : coef = scale*log2(e), pen = 0        masked key : coef = 0, pen = -1e9*log2(e)
+//   key >= Sk  : coef = 0, pen = -inf  (tile padding)
+constexpr int MAXK = 2048 + 64;
+constexpr int MERGE_FLOATS = (KW - 1) * QW * 130 * 64;
+static_assert(MERGE_FLOATS * 4 <= LDS_KV, "the merge area reuses the K/V stages");
 
 struct AttnArgs {
   const bf16_t* Q; long ldq;
@@ -42,24 +66,38 @@ struct AttnArgs {
   int q_tiles, dbg;
 };
 
-template <int QW, int KW, bool QMASK>
-__global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p) {
-  constexpr int NT = 64 * QW * KW;
-  constexpr int BN = 32 * KW;                       // keys per tile
-  constexpr int K_ELEMS = BN * SKS, V_ELEMS = BN * SVS;
-  constexpr int STAGE = K_ELEMS + V_ELEMS;
-  constexpr int CH = BN * (DK / 8) / NT;            // 16-byte chunks per thread per operand per tile
-  static_assert(BN * (DK / 8) % NT == 0, "tile must divide evenly");
-  constexpr int MERGE_FLOATS = (KW > 1) ? (KW - 1) * QW * 130 * 64 : 0;
-  constexpr int LDS_BYTES = (2 * STAGE * 2 > MERGE_FLOATS * 4) ? 2 * STAGE * 2 : MERGE_FLOATS * 4;
-  // per-key softmax coefficients of this batch row: score2 = fma(q.k, coef[key], pen[key]) in the log2 domain
-  //   valid key  : coef = scale*log2(e), pen = 0        masked key : coef = 0, pen = -1e9*log2(e)
-  //   key >= Sk  : coef = 0, pen = -inf  (tile padding)
-  constexpr int MAXK = 2048 + 64;
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_BYTES + 2 * MAXK * 4];
-  float* s_coef = reinterpret_cast<float*>(smem_raw + LDS_BYTES);
+// LDS reads the compiler must not see (see the header); `addr` is a byte address in LDS.
+template <int OFF>
+__device__ __forceinline__ bf16x4 asm_tr4(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 asm_ldsf4(unsigned addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ float pair_max(float v) {   // max over lanes l and l^32, on both
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <bool QMASK>
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_KV + 2 * MAXK * 4];
+  float* s_coef = reinterpret_cast<float*>(smem_raw + LDS_KV);
   float* s_pen = s_coef + MAXK;
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   constexpr float RESCALE_THR = 8.f;   // lazy rescale: keep a stale running max while it lags by < 2^8
 
@@ -87,8 +125,8 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
   const bf16_t* __restrict__ Vg = p.V + (long)b * p.Sk * p.ldv + hd * DK;
 
   constexpr bool key_mask = !QMASK;    // same mask for every query row (or none) -> LDS coefficients
-  const int padded = ((p.Sk + BN - 1) / BN) * BN;
-  for (int i = tid; i < padded; i += NT) {
+  const int nt = (p.Sk + BN - 1) / BN;
+  for (int i = tid; i < nt * BN; i += NT) {
     const bool in = i < p.Sk;
     bool keep = in;
     if constexpr (key_mask) keep = in && (p.mask == nullptr || p.mask[(long)b * p.mask_sb + i] != 0);
@@ -103,161 +141,305 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     const bf16_t* qp = p.Q + ((long)b * p.Sq + (q_ok ? q_row : 0)) * p.ldq + hd * DK + 8 * h;
 #pragma unroll
     for (int s = 0; s < DK / 16; ++s) qf[s] = q_ok ? *reinterpret_cast<const bf16x8*>(qp + 16 * s) : zero_bf16x8();
+    // Loop invariant and only ever an MFMA B operand: pin the 64 registers to the accumulator half of the register file
+    // (MFMA reads A/B from there directly), which leaves the arch VGPRs to the K / V^T fragments and the softmax.
+#pragma unroll
+    for (int s = 0; s < DK / 16; ++s) asm volatile("" : "+a"(qf[s]));
   }
 
-  // K/V staging: direct-to-LDS loads (no staging registers, no ds_write).  Wave w fills tile rows [16w, 16w+16) of
-  // both operands, two rows (1 KiB) per instruction: lane l writes chunk (l & 31) of row 16w + 2i + (l >> 5) and
-  // therefore fetches the swizzled source chunk of that row.
-  constexpr int NW = QW * KW;
-  constexpr int GL = BN / 2 / NW;                      // glds instructions per operand per wave per tile
-  static_assert(BN % (2 * NW) == 0 && (BN / NW) % 16 == 0, "a wave fills whole groups of 16 rows");
+  // ---- K/V staging: direct-to-LDS loads (no staging registers, no ds_write).  Wave w fills tile rows [16w, 16w+16) of
+  // an operand, two rows (1 KiB) per instruction: lane l writes chunk (l & 31) of row 16w + 2i + (l >> 5).  Rows are
+  // XOR-swizzled in LDS -- K: 16-byte chunk ^= row & 15 (the 16 rows of a ds_read_b128 group hit 16 different slots),
+  // V: chunk ^= (row & 3) << 2 (the 4 rows of a transposed-read block hit 4 different bank quarters) -- and the
+  // swizzle is applied on the SOURCE address.
+  constexpr int GL = BN / 2 / (QW * KW);               // = 8 instructions per wave per operand per tile
   const int hi = lane >> 5, pch = lane & 31;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: tile row bases become scalar
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wrow = wave_s * (BN / (QW * KW));
+  int koff[GL], voff[2];                               // lane part of the source offsets (elements)
+#pragma unroll
+  for (int i = 0; i < GL; ++i) koff[i] = hi * (int)p.ldk + ((pch ^ (2 * i + hi)) << 3);
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) voff[bb] = hi * (int)p.ldv + ((pch ^ ((2 * bb + hi) << 2)) << 3);
   auto glds16 = [](const bf16_t* src, bf16_t* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  auto issue_tile = [&](int k0, int buf) {
-    bf16_t* sK = smem + buf * STAGE;
-    bf16_t* sV = sK + K_ELEMS;
-    const int wrow = wave_s * (BN / NW);
+  auto issue_k = [&](int t, int buf) {
+    bf16_t* sK = smem + buf * VST + wrow * DK;
+    const int k0 = t * BN;
     if (k0 + BN <= p.Sk) {
-      const bf16_t* Kt = Kg + (long)(k0 + wrow) * p.ldk;      // uniform
-      const bf16_t* Vt = Vg + (long)(k0 + wrow) * p.ldv;
-      const int klane = hi * (int)p.ldk, vlane = hi * (int)p.ldv;
+      const bf16_t* Kt = Kg + (long)(k0 + wrow) * p.ldk;          // uniform
 #pragma unroll
-      for (int i = 0; i < GL; ++i) {
-        const int r = 2 * i + hi;                      // row inside the wave's group (== row & 15, == row & 3 mod 4)
-        glds16(Kt + (long)(2 * i) * p.ldk + (klane + ((pch ^ (r & 15)) << 3)), sK + (wrow + 2 * i) * DK);
-        glds16(Vt + (long)(2 * i) * p.ldv + (vlane + ((pch ^ ((r & 3) << 2)) << 3)), sV + (wrow + 2 * i) * DK);
-      }
+      for (int i = 0; i < GL; ++i) glds16(Kt + (long)(2 * i) * p.ldk + koff[i], sK + 2 * i * DK);
     } else {   // ragged last tile: clamp the key row (its score gets pen = -inf, so P is exactly 0 there)
 #pragma unroll
       for (int i = 0; i < GL; ++i) {
         const int r = 2 * i + hi;
         const long gr = min(k0 + wrow + r, p.Sk - 1);
-        glds16(Kg + gr * p.ldk + ((pch ^ (r & 15)) << 3), sK + (wrow + 2 * i) * DK);
-        glds16(Vg + gr * p.ldv + ((pch ^ ((r & 3) << 2)) << 3), sV + (wrow + 2 * i) * DK);
+        glds16(Kg + gr * p.ldk + ((pch ^ r) << 3), sK + 2 * i * DK);
       }
     }
   };
+  auto issue_v = [&](int t, int buf) {
+    bf16_t* sV = smem + (2 + buf) * VST + wrow * DK;
+    const int k0 = t * BN;
+    if (k0 + BN <= p.Sk) {
+      const bf16_t* Vt = Vg + (long)(k0 + wrow) * p.ldv;          // uniform
+#pragma unroll
+      for (int i = 0; i < GL; ++i) glds16(Vt + (long)(2 * i) * p.ldv + voff[i & 1], sV + 2 * i * DK);
+    } else {   // ragged: the probability is exactly 0 there, but the data must be finite
+#pragma unroll
+      for (int i = 0; i < GL; ++i) {
+        const int r = 2 * i + hi;
+        const long gr = min(k0 + wrow + r, p.Sk - 1);
+        glds16(Vg + gr * p.ldv + ((pch ^ ((r & 3) << 2)) << 3), sV + 2 * i * DK);
+      }
+    }
+  };
+  issue_k(0, 0);
+  issue_v(0, 0);
+  if (nt > 1) issue_k(1, 1);
 
   f32x16 o[DK / 32];
 #pragma unroll
   for (int d = 0; d < DK / 32; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;   // log2-domain running max (possibly stale by < RESCALE_THR) and sum
+  float m_run = -INFINITY, l_run = 0.f;   // log2-domain running max (possibly stale by < RESCALE_THR); l_run is this
+                                          // lane's half of the row sum (the two 32-lane halves are added at the end)
 
-  const int nt = (p.Sk + BN - 1) / BN;
-  issue_tile(0, 0);
-  __syncthreads();   // (waits for the direct-to-LDS loads: they count on vmcnt)
-
-  // swizzled fragment addressing (per-lane constants)
-  const int kx = r32 & 15;                              // K: chunk ^= row & 15 ; logical chunk of step st is 2 st + h
-  const int k_xs = kx >> 1, k_lo = ((h ^ (kx & 1)) << 3) + (32 * ki + r32) * DK;
-  const int v_lo = (32 * ki + 4 * h + q4) * DK + ((2 * g1 + (p4 >> 1)) << 3) + ((p4 & 1) << 2);   // V: chunk ^= (row & 3) << 2
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const int k0 = t * BN;
-    if (t + 1 < nt && p.dbg != 1) issue_tile(k0 + BN, cur ^ 1);
-    const bf16_t* sK = smem + cur * STAGE;
-    const bf16_t* sV = sK + K_ELEMS;
-
-    // ---- S^T = K . Q^T for this wave's 32 keys
-    f32x16 s;
+  // per-lane LDS byte addresses
+  //   V^T fragments: row 32 ki + 4 h + q4 (+16 ks, +8 for the second half), chunk 4 (d ^ (row & 3)) + 2 g1 + (p4 >> 1)
+  unsigned v_addr[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    const bf16_t* kbase = sK + k_lo;
-    {   // all 16 K fragments are requested before the MFMA chain starts, so LDS latency is paid once per tile
-      bf16x8 kf[DK / 16];
+  for (int dd = 0; dd < 4; ++dd)
+    v_addr[dd] = lds0 + 2 * VST * 2 + 2 * ((32 * ki + 4 * h + q4) * DK + ((dd ^ q4) << 5) + ((2 * g1 + (p4 >> 1)) << 3) + ((p4 & 1) << 2));
+  //   K fragments: row 32 ki + r32, logical chunk 2 st + h at physical chunk (2 st + h) ^ (row & 15); steps st and st + 8
+  //   are 256 bytes apart, so 8 addresses + an immediate cover the 16 steps
+  unsigned k_addr[8];
 #pragma unroll
-      for (int st = 0; st < DK / 16; ++st) kf[st] = *reinterpret_cast<const bf16x8*>(kbase + ((st ^ k_xs) << 4));
-#pragma unroll
-      for (int st = 0; st < DK / 16; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
-    }
+  for (int st = 0; st < 8; ++st)
+    k_addr[st] = lds0 + 2 * ((32 * ki + r32) * DK + (((2 * st + h) ^ (r32 & 15)) << 3));
+  unsigned c_addr = lds0 + LDS_KV + 4 * (32 * ki + 4 * h);      // coefficients of this lane's keys in tile 0
 
-    // ---- log2-domain scores: one FMA per element with the per-key coefficient / penalty (4 consecutive keys per
-    // 16-byte LDS read); then the online softmax on per-lane state (this lane's query row)
-    const int key0 = k0 + 32 * ki + 4 * h;
+  // scale + mask the raw scores of one tile (accumulator -> log2-domain scores), and their maximum over the lane pair
+  auto scale_scores = [&](const f32x16& raw, f32x16& sc, const int k0, const f32x4 (&cf)[4], const f32x4 (&pn)[4]) {
     float m_tile = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 cf = *reinterpret_cast<const f32x4*>(s_coef + key0 + 8 * g);
-      const f32x4 pn = *reinterpret_cast<const f32x4*>(s_pen + key0 + 8 * g);
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v = fmaf(s[4 * g + j], cf[j], pn[j]);
+        float v = fmaf(raw[4 * g + j], cf[g][j], pn[g][j]);
         if constexpr (QMASK) {   // per-query mask (not the encoder's case): exact masked_fill semantics
-          const int key = key0 + 8 * g + j;
+          const int key = k0 + 32 * ki + 4 * h + 8 * g + j;
           if (key < p.Sk && !mrow[key]) v = NEG_MASK * LOG2E;
         }
-        s[4 * g + j] = v;
+        sc[4 * g + j] = v;
         m_tile = fmaxf(m_tile, v);
       }
-    }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    // lazy rescale (only when some row's max grew by more than RESCALE_THR): everything accumulated so far is at
-    // the old max and P of this tile has not been exponentiated yet, so O and l are scaled exactly once
+    return pair_max(m_tile);
+  };
+  // lazy rescale (only when some row's max grew by more than RESCALE_THR): everything accumulated so far is at the old
+  // max and P of the new tile has not been exponentiated yet, so O and l are scaled exactly once
+  auto maybe_rescale = [&](const float m_tile, const bool have_o) {
     if (__any(m_tile > m_run + RESCALE_THR)) {
       const float m_new = fmaxf(m_run, m_tile);
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
-      if (t > 0) {
-        // O^T lives in the accumulator file (MFMA C/D).  The rescale is rare; it is written with AGPR-constrained
-        // asm so the compiler keeps the 128 accumulators there instead of copying them to VGPRs on every tile.
-#pragma unroll
-        for (int d = 0; d < DK / 32; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float tmp;
-            asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %2, %1\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
-                         : "+a"(o[d][r]), "=&v"(tmp) : "v"(alpha));
-          }
+      if (have_o) {
+        // O^T lives in the accumulator file (MFMA C/D).  The rescale is rare; each d-tile is handed to the asm as ONE
+        // 16-register operand bound to a fixed accumulator range, so the compiler neither splits the tuples nor copies
+        // the 128 accumulators to VGPRs around the loop.
+#define BMHRL_RESCALE_TILE(D, A0, A1, A2, A3, A4, A5, A6, A7, A8, A9, A10, A11, A12, A13, A14, A15, RANGE)                  \
+        {                                                                                                                   \
+          float tmp;                                                                                                        \
+          asm volatile(BMHRL_RS1(A0) BMHRL_RS1(A1) BMHRL_RS1(A2) BMHRL_RS1(A3) BMHRL_RS1(A4) BMHRL_RS1(A5) BMHRL_RS1(A6)      \
+                       BMHRL_RS1(A7) BMHRL_RS1(A8) BMHRL_RS1(A9) BMHRL_RS1(A10) BMHRL_RS1(A11) BMHRL_RS1(A12) BMHRL_RS1(A13) \
+                       BMHRL_RS1(A14) BMHRL_RS1(A15)                                                                        \
+                       : "+{" RANGE "}"(o[D]), "=&v"(tmp) : "v"(alpha));                                                    \
+        }
+#define BMHRL_RS1(A) "v_accvgpr_read_b32 %1, " #A "\n\ts_nop 1\n\tv_mul_f32 %1, %2, %1\n\ts_nop 1\n\tv_accvgpr_write_b32 " #A ", %1\n\t"
+        BMHRL_RESCALE_TILE(0, a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, "a[0:15]")
+        BMHRL_RESCALE_TILE(1, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27, a28, a29, a30, a31, "a[16:31]")
+        BMHRL_RESCALE_TILE(2, a32, a33, a34, a35, a36, a37, a38, a39, a40, a41, a42, a43, a44, a45, a46, a47, "a[32:47]")
+        BMHRL_RESCALE_TILE(3, a48, a49, a50, a51, a52, a53, a54, a55, a56, a57, a58, a59, a60, a61, a62, a63, "a[48:63]")
+        BMHRL_RESCALE_TILE(4, a64, a65, a66, a67, a68, a69, a70, a71, a72, a73, a74, a75, a76, a77, a78, a79, "a[64:79]")
+        BMHRL_RESCALE_TILE(5, a80, a81, a82, a83, a84, a85, a86, a87, a88, a89, a90, a91, a92, a93, a94, a95, "a[80:95]")
+        BMHRL_RESCALE_TILE(6, a96, a97, a98, a99, a100, a101, a102, a103, a104, a105, a106, a107, a108, a109, a110, a111, "a[96:111]")
+        BMHRL_RESCALE_TILE(7, a112, a113, a114, a115, a116, a117, a118, a119, a120, a121, a122, a123, a124, a125, a126, a127, "a[112:127]")
+#undef BMHRL_RS1
+#undef BMHRL_RESCALE_TILE
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
       }
       m_run = m_new;
     }
+  };
+  auto read_coef = [&](const unsigned a, f32x4 (&cf)[4], f32x4 (&pn)[4]) {
+    cf[0] = asm_ldsf4<0>(a);  cf[1] = asm_ldsf4<32>(a);  cf[2] = asm_ldsf4<64>(a);  cf[3] = asm_ldsf4<96>(a);
+    pn[0] = asm_ldsf4<MAXK * 4>(a);      pn[1] = asm_ldsf4<MAXK * 4 + 32>(a);
+    pn[2] = asm_ldsf4<MAXK * 4 + 64>(a); pn[3] = asm_ldsf4<MAXK * 4 + 96>(a);
+  };
+  // tiles whose 32 keys (of this wave) are all valid and unmasked -- nearly all of them -- only need score * c
+  const float c_log2 = p.scale * LOG2E;
+  auto scale_scores_fast = [&](const f32x16& raw, f32x16& sc) {
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc[r] = raw[r] * c_log2;
+      m_tile = fmaxf(m_tile, sc[r]);
+    }
+    return pair_max(m_tile);
+  };
+
+  // ---- S^T chain of one tile: K fragments by ds_read_b128 (asm), first half of the chain starts as soon as the first 8
+  // fragments are there; `mid` runs between the two halves (it issues the V^T reads of the tile in flight), `step(st)`
+  // after every MFMA (the exponentials of the previous tile hide under the chain)
+  f32x16 s_acc, sc;
+  bf16x8 kf[DK / 16];
+  auto qk_issue = [&](const unsigned koffs) {
+#pragma unroll
+    for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(kf[st]) : "v"(k_addr[st] + koffs));
+#pragma unroll
+    for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(kf[8 + st]) : "v"(k_addr[st] + koffs));
+  };
+  auto qk_chain = [&](auto&& mid, auto&& step) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
+      step(st);
+    }
+    mid();
+    // in-order returns: at most 15 younger reads outstanding means the 16 K fragments are all there
+    asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[8]), "+v"(kf[9]), "+v"(kf[10]), "+v"(kf[11]), "+v"(kf[12]), "+v"(kf[13]), "+v"(kf[14]), "+v"(kf[15]));
+#pragma unroll
+    for (int st = 8; st < 16; ++st) {
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
+      step(st);
+    }
+  };
+
+
+  __syncthreads();   // coefficients written; also drains the first K/V stages (direct-to-LDS loads count on vmcnt)
+  qk_issue(0u);
+  qk_chain([] {}, [](int) {});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();      // every wave is done with K stage 0: the loop refills it right away
+  asm volatile("" ::: "memory");
+  uint64_t slow_bits = 0;            // bit t: tile t has a masked or padding key among this wave's 32 (wave-uniform)
+  if constexpr (QMASK) {
+    slow_bits = ~0ull;
+  } else {
+    for (int t = 0; t < nt; ++t)
+      if (__any(s_pen[t * BN + 32 * ki + r32] != 0.f)) slow_bits |= 1ull << t;
+  }
+  {
+    f32x4 cf[4], pn[4];
+    read_coef(c_addr, cf, pn);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pn[3]));
+    const float m_tile = scale_scores(s_acc, sc, 0, cf, pn);
+    maybe_rescale(m_tile, false);
+  }
+
+  // ---- main loop.  Iteration t:  phase 1  P(t) = exp2(scores(t) - max)  ||  S^T(t+1) = K(t+1) . Q^T (K fragments are
+  // refilled with tile t+2 as they are consumed);  phase 2  O^T += V^T(t) . P^T(t)  ||  scores(t+1), row max, rescale.
+  bf16x8 vf[4][2], pf[2];
+  auto read_vt = [&](const unsigned soff, auto half) {      // V^T fragments of d-tiles 4*half .. 4*half+3
+    constexpr int HOFF = decltype(half)::value * 256;
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+      const unsigned a = v_addr[dd] + soff;
+      vf[dd][0] = join8(asm_tr4<HOFF>(a), asm_tr4<HOFF + 8 * DK * 2>(a));
+      vf[dd][1] = join8(asm_tr4<HOFF + 16 * DK * 2>(a), asm_tr4<HOFF + 24 * DK * 2>(a));
+    }
+  };
+  auto wait_vt = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]),
+                   "+v"(vf[3][0]), "+v"(vf[3][1]));
+  };
+  auto pv = [&](const int d0) {
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        o[d0 + dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd][ks], pf[ks], o[d0 + dd], 0, 0, 0);
+  };
+  auto pack_p = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pf[0][j] = (bf16_t)sc[j];
+      pf[1][j] = (bf16_t)sc[8 + j];
+    }
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+
+  for (int t = 0; t + 1 < nt; ++t) {
+    const int cur = t & 1;                     // V stage of tile t == K stage of tile t+2; K(t+1), V(t+1) use stage cur^1
+    if (p.dbg != 1) {                          // (tuning aid: dbg 1 times the loop without its loads)
+      if (t + 2 < nt) issue_k(t + 2, cur);     // K(t) was read in the previous iteration, V(t-1) too
+      issue_v(t + 1, cur ^ 1);
+    }
+    const unsigned soff = (unsigned)cur * (VST * 2);
+    {
+      const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+      float psum = 0.f;
+      qk_issue((unsigned)(cur ^ 1) * (VST * 2));
+      qk_chain([&] { read_vt(soff, H0{}); },     // V^T(t), d-tiles 0..3: wanted at the start of phase 2
+               [&](const int st) {               // one exponential of tile t under every MFMA of tile t+1
+                 const float e = __builtin_amdgcn_exp2f(sc[st] - m_use);
+                 sc[st] = e;
+                 psum += e;
+               });
+      l_run += psum;
+      pack_p();
+    }
+    wait_vt();
+    pv(0);
+    read_vt(soff, H1{});
+    c_addr += BN * 4;
+    float m_tile = scale_scores_fast(s_acc, sc);   // independent of the MFMAs around it: the VALU work hides under them
+    wait_vt();
+    pv(4);
+    if ((slow_bits >> (t + 1)) & 1) {              // wave-uniform, rare: redo the scores with the per-key coefficients
+      f32x4 cf[4], pn[4];
+      read_coef(c_addr, cf, pn);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pn[3]));
+      m_tile = scale_scores(s_acc, sc, (t + 1) * BN, cf, pn);
+    }
+    maybe_rescale(m_tile, true);
+
+    // ---- the loads issued at the top of this iteration (K tile t+2, V tile t+1) have had the whole iteration to land;
+    // the barrier publishes them and retires K stage cur^1 / V stage cur for the next refill
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  {   // last tile: exponentials and O^T only
+    const unsigned soff = (unsigned)((nt - 1) & 1) * (VST * 2);
+    read_vt(soff, H0{});
     const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(s[r] - m_use);
-      s[r] = e;
+      const float e = __builtin_amdgcn_exp2f(sc[r] - m_use);
+      sc[r] = e;
       psum += e;
     }
-    psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
-    bf16x8 pf[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pf[0][j] = (bf16_t)s[j];
-      pf[1][j] = (bf16_t)s[8 + j];
-    }
-
-    // ---- O^T += V^T . P^T ; V^T fragments come transposed out of the row-major V tile
-    const bf16_t* vbase = sV + v_lo;
-#pragma unroll
-    for (int dh = 0; dh < DK / 32; dh += 4) {   // V^T fragments of four d-tiles are requested ahead of their 8 MFMAs
-      bf16x8 vf[4][2];
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) {
-        const bf16_t* vd = vbase + (((dh + dd) ^ q4) << 5);   // physical chunk 4 (d ^ (row & 3)) + ...
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16_t* vp = vd + (16 * ks) * SVS;
-          vf[dd][ks] = join8(lds_read_tr4(vp), lds_read_tr4(vp + 8 * SVS));
-        }
-      }
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          o[dh + dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd][ks], pf[ks], o[dh + dd], 0, 0, 0);
-    }
-
-    __syncthreads();   // everyone is done with buffer `cur`, and the loads into the other buffer have landed
+    pack_p();
+    wait_vt();
+    pv(0);
+    read_vt(soff, H1{});
+    wait_vt();
+    pv(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();             // every wave is done with the V stages: the merge below reuses them
+    asm volatile("" ::: "memory");
   }
 
   // ---- merge the KW partial states of each query block (ki > 0 publish through LDS, ki == 0 combines)
@@ -292,6 +474,7 @@ __global__ __launch_bounds__(64 * QW * KW) void attn_fwd_kernel(const AttnArgs p
     }
   }
 
+  l_run += __shfl_xor(l_run, 32, 64);   // the two 32-lane halves hold disjoint keys of the same query row
   if (ki == 0 && q_ok) {
     const float inv = 1.0f / l_run;
     if (h == 0) {
@@ -383,12 +566,11 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
   a.O = (bf16_t*)O; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
   a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev;
-  constexpr int QW = 2, KW = 2;
   a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
   a.dbg = getenv("BMHRL_ATTN_DBG") ? atoi(getenv("BMHRL_ATTN_DBG")) : 0;
-  dim3 grid((unsigned)(B * H * a.q_tiles)), block(64 * QW * KW);
-  if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<QW, KW, true>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<QW, KW, false>), grid, block, 0, (hipStream_t)stream, a);
+  dim3 grid((unsigned)(B * H * a.q_tiles)), block(NT);
+  if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
   return hip_status(hipGetLastError());
 }
 
