@@ -10,7 +10,9 @@ LIB = os.path.join(CSRC, "libbmhrl_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "critic.hip"]
 # attention.hip: the eight 16-register O^T accumulators are loop-carried vector PHIs; AMDGPUCodeGenPrepare would break
 # them into 128 scalar (VGPR) PHIs, i.e. 128 accumulator<->VGPR copies per key tile around the MFMAs.
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]}
+# gemm.hip: same for the MFMA tile accumulators of the main loop (1-3 % on the large shapes).
+_VECTOR_PHIS = ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]
+EXTRA_FLAGS = {"attention.hip": _VECTOR_PHIS, "gemm.hip": _VECTOR_PHIS}
 
 
 def hipcc() -> str:

@@ -91,6 +91,74 @@ class DropoutSeeds:
 SEEDS = DropoutSeeds()
 
 
+# ------------------------------------------------------------------------------------------------ step-scoped scratch
+class StepScratch:
+    """Zero-initialised scratch handed out inside ONE training step (between begin_step() and end_step(), as
+    bmhrl_amd.train.CaptionTrainer does), so that a step issues one fill instead of ~250:
+
+      * f32(): slices of one fp32 arena that begin_step() zeroes with a single launch -- weight / bias / LayerNorm
+        gradient accumulators (split-K GEMMs and column sums add into them with atomics);
+      * bf16(): (rows, pad8(cols)) bf16 operand buffers whose padding columns must be zero.  Kernels never write the
+        padding, so a buffer zeroed when it was created stays valid: the pool hands the same buffers out again, in
+        the same order, every step.
+
+    Outside a step (unit tests, inference) both fall back to freshly zeroed tensors.  The first step sizes the arena,
+    so everything is allocated before a HIP graph capture of the step (capture runs warm-up steps first)."""
+
+    def __init__(self):
+        self.armed = False
+        self.arena: Optional[torch.Tensor] = None
+        self.off = 0
+        self.spill = 0
+        self.need = 0
+        self.pool = {}
+        self.cursor = {}
+
+    def begin_step(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            return
+        if self.arena is None or self.arena.device != device or self.arena.numel() < self.need:
+            self.arena = torch.zeros(self.need, device=device) if self.need else None
+        elif self.off:
+            self.arena[:self.off].zero_()
+        self.off = self.spill = 0
+        self.cursor = {}
+        self.armed = True
+
+    def end_step(self):
+        self.need = max(self.need, self.off + self.spill)
+        self.armed = False
+
+    def f32(self, *shape, device) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) & ~3
+        a = self.arena
+        if not self.armed or a is None or a.device != device or self.off + n4 > a.numel():
+            if self.armed:
+                self.spill += n4
+            return torch.zeros(*shape, device=device)
+        t = a[self.off:self.off + n].view(*shape)
+        self.off += n4
+        return t
+
+    def bf16(self, rows: int, cols: int, device) -> torch.Tensor:
+        if cols % 8 == 0 or not self.armed:
+            return ops.bf16_zeros(rows, cols, device)
+        key = (rows, cols, device)
+        lst = self.pool.setdefault(key, [])
+        i = self.cursor.get(key, 0)
+        if i == len(lst):
+            lst.append(ops.bf16_zeros(rows, cols, device))
+        self.cursor[key] = i + 1
+        return lst[i]
+
+
+SCRATCH = StepScratch()
+
+
 def _mask_u8(mask: Optional[torch.Tensor]):
     """(B,1,Sk) or (B,Sq,Sk) bool/byte mask -> contiguous byte tensor + (batch stride, row stride)."""
     if mask is None:
@@ -175,12 +243,12 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
     dev = dyb.device
     dw = db = None
     if need_dw:
-        dw = torch.zeros(N, K, device=dev)   # zeroed: the long row reduction may run split-K with fp32 atomics
+        dw = SCRATCH.f32(N, K, device=dev)   # zeroed: the long row reduction may run split-K with fp32 atomics
         ops.gemm(dyb, xb, N, K, rows, lda=ldy, ldb=ldx, a_off=dy_off, b_off=x_off, a_trans=True, b_trans=True, C_f32=dw, ldc=K,
                  allow_split_k=True)
     if need_db:
-        db = torch.empty(N, device=dev)
-        ops.colsum_bf16(dyb, ldy, db, False, rows, N, dy_off=dy_off)
+        db = SCRATCH.f32(N, device=dev)
+        ops.colsum_bf16(dyb, ldy, db, True, rows, N, dy_off=dy_off)
     if need_dx:
         ops.gemm(dyb, wb, rows, K, N, lda=ldy, ldb=wb.shape[1], a_off=dy_off, b_off=w_off, b_trans=True, C_f32=dx_f32,
                  ldc=K, C_bf16=dx_bf16, ldcb=lddxb, epilogue=dx_epilogue, alpha=dx_alpha, aux=dx_aux, ldaux=ldaux,
@@ -207,7 +275,7 @@ class MHAFn(torch.autograd.Function):
         self_att = kv_in is None
         has_ln = ln_w is not None
         ldx = pad8(dq)
-        xb = ops.bf16_zeros(rows_q, dq, dev)
+        xb = SCRATCH.bf16(rows_q, dq, dev)
         mean = rstd = None
         if has_ln:
             mean = torch.empty(rows_q, device=dev)
@@ -230,7 +298,7 @@ class MHAFn(torch.autograd.Function):
             _, Sk, dkv = kv_in.shape
             rows_k = B * Sk
             kv_in = kv_in.contiguous()
-            kvb = ops.bf16_zeros(rows_k, dkv, dev)
+            kvb = SCRATCH.bf16(rows_k, dkv, dev)
             ops.cast_bf16(kv_in, dkv, kvb, kvb.shape[1], rows_k, dkv)
             w_q = SHADOWS.weight(wq)
             w_kv = SHADOWS.weight(wk, wv)
@@ -268,7 +336,7 @@ class MHAFn(torch.autograd.Function):
         dy = dy.contiguous()
         keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         # d(out) through the residual-branch dropout -> bf16
-        dyb = ops.bf16_zeros(rows_q, dq, dev)
+        dyb = SCRATCH.bf16(rows_q, dq, dev)
         ops.cast_bf16(dy, dq, dyb, ldx, rows_q, dq, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
         # linear_d2Q backward; its dx is d(attention output), taken back through the output dropout in the epilogue
         dOb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
@@ -316,8 +384,8 @@ class MHAFn(torch.autograd.Function):
         if has_ln:
             if dxn is not None:
                 dx = torch.empty(B, Sq, dq, device=dev)
-                dlnw = torch.zeros(dq, device=dev) if need[2] else None
-                dlnb = torch.zeros(dq, device=dev) if need[3] else None
+                dlnw = SCRATCH.f32(dq, device=dev) if need[2] else None
+                dlnb = SCRATCH.f32(dq, device=dev) if need[3] else None
                 ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy if residual else None, dlnw, dlnb, rows_q, dq)
         elif need[0]:
             dx = dxn.view(B, Sq, dq)
@@ -384,13 +452,13 @@ class FFNFn(torch.autograd.Function):
         dff = w1.shape[0]
         x = x.contiguous()
         ldx = pad8(d)
-        xb = ops.bf16_zeros(rows, d, dev)
+        xb = SCRATCH.bf16(rows, d, dev)
         mean = torch.empty(rows, device=dev)
         rstd = torch.empty(rows, device=dev)
         ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), xb, ldx, None, mean, rstd, rows, d)
         s_in, s_res = SEEDS.next(), SEEDS.next()
         wb1, wb2 = SHADOWS.weight(w1), SHADOWS.weight(w2)
-        hb = ops.bf16_zeros(rows, dff, dev)
+        hb = SCRATCH.bf16(rows, dff, dev)
         ops.gemm(xb, wb1, rows, dff, d, lda=ldx, ldb=wb1.shape[1], C_bf16=hb, ldcb=hb.shape[1], bias=b1.detach(), relu=True,
                  dropout_p=p_drop, seed=s_in, seed_dev=SEEDS.dev)
         y = torch.empty(B, S, d, device=dev)
@@ -409,11 +477,11 @@ class FFNFn(torch.autograd.Function):
         ldx = pad8(d)
         need = ctx.needs_input_grad
         dy = dy.contiguous()
-        dyb = ops.bf16_zeros(rows, d, dev)
+        dyb = SCRATCH.bf16(rows, d, dev)
         ops.cast_bf16(dy, d, dyb, ldx, rows, d, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
         wb1, wb2 = SHADOWS.weight(w1), SHADOWS.weight(w2)
         # dz = (dy W2) * [h > 0] / (1-p): h already carries relu and the inner dropout mask
-        dzb = ops.bf16_zeros(rows, dff, dev)
+        dzb = SCRATCH.bf16(rows, dff, dev)
         keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         dw2, db2 = _linear_bwd(dyb, ldx, rows, d, hb, hb.shape[1], dff, wb2, need_dw=need[5], need_db=need[6], need_dx=True,
                                dx_bf16=dzb, lddxb=dzb.shape[1], dx_epilogue=ops.EPI_RELU_BWD, dx_alpha=keep, dx_aux=hb,
@@ -422,8 +490,8 @@ class FFNFn(torch.autograd.Function):
         dw1, db1 = _linear_bwd(dzb, dzb.shape[1], rows, dff, xb, ldx, d, wb1, need_dw=need[3], need_db=need[4], need_dx=True,
                                dx_f32=dxn)
         dx = torch.empty(B, S, d, device=dev)
-        dlnw = torch.zeros(d, device=dev) if need[1] else None
-        dlnb = torch.zeros(d, device=dev) if need[2] else None
+        dlnw = SCRATCH.f32(d, device=dev) if need[1] else None
+        dlnb = SCRATCH.f32(d, device=dev) if need[2] else None
         ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy, dlnw, dlnb, rows, d)
         return dx, dlnw, dlnb, dw1, db1, dw2, db2, None
 
@@ -440,7 +508,7 @@ class LinearFn(torch.autograd.Function):
         rows = x.numel() // K
         N = w.shape[0]
         x2 = x.contiguous().view(rows, K)
-        xb = ops.bf16_zeros(rows, K, dev)
+        xb = SCRATCH.bf16(rows, K, dev)
         ops.cast_bf16(x2, K, xb, xb.shape[1], rows, K)
         wb = SHADOWS.weight(w)
         y = torch.empty(rows, N, device=dev)
@@ -464,7 +532,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = torch.where(y != 0, dy2 * keep, torch.zeros_like(dy2)) if relu else None
             if dy2 is None:
                 dy2 = dy.contiguous().view(rows, N)
-        dyb = ops.bf16_zeros(rows, N, dev)
+        dyb = SCRATCH.bf16(rows, N, dev)
         drop = p_drop if not relu else 0.0
         ops.cast_bf16(dy2, N, dyb, dyb.shape[1], rows, N, dropout_p=drop, seed=seed, seed_dev=SEEDS.dev)
         wb = SHADOWS.weight(w)
@@ -497,8 +565,8 @@ class LayerNormFn(torch.autograd.Function):
         rows = x.numel() // D
         need = ctx.needs_input_grad
         dx = torch.empty_like(x)
-        dw = torch.zeros(D, device=x.device) if need[1] else None
-        db = torch.zeros(D, device=x.device) if need[2] else None
+        dw = SCRATCH.f32(D, device=x.device) if need[1] else None
+        db = SCRATCH.f32(D, device=x.device) if need[2] else None
         ops.layernorm_bwd(dy.contiguous(), x, w, mean, rstd, dx, None, dw, db, rows, D)
         return dx, dw, db
 
@@ -522,7 +590,7 @@ class GateFn(torch.autograd.Function):
         D = cv.shape[-1]
         rows = cv.numel() // D
         dcv, dca = torch.empty_like(cv), torch.empty_like(ca)
-        da = torch.zeros(1, device=cv.device)
+        da = SCRATCH.f32(1, device=cv.device)
         ops.gate_bwd(dout.contiguous(), cv, ca, a_v, dcv, dca, da, rows, D)
         return dcv, dca, da
 
@@ -557,10 +625,10 @@ class EmbedFn(torch.autograd.Function):
         dout = dout.contiguous()
         if p_drop > 0:
             # regenerate the forward mask: cast kernel applies it, then back to fp32 rows for the scatter
-            tmp = ops.bf16_zeros(B * L, D, dev)
+            tmp = SCRATCH.bf16(B * L, D, dev)
             ops.cast_bf16(dout, D, tmp, tmp.shape[1], B * L, D, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
             dout = tmp[:, :D].float().contiguous()
-        dtable = torch.zeros(V, D, device=dev)
+        dtable = SCRATCH.f32(V, D, device=dev)
         ops.embed_bwd(tok, tok2, mix, dout, dtable, B, L, D, math.sqrt(D))
         return dtable, None, None, None, None, None
 
@@ -585,7 +653,7 @@ class ExpandGoalsFn(torch.autograd.Function):
     def backward(ctx, dout):
         B, L, D = ctx.cfg
         (src,) = ctx.saved_tensors
-        dx = torch.zeros(B, L, D, device=dout.device)
+        dx = SCRATCH.f32(B, L, D, device=dout.device)
         ops.scatter_add_rows(dout.contiguous(), src, dx, B * L, D)
         return dx, None
 
@@ -600,7 +668,7 @@ class WorkerHeadFn(torch.autograd.Function):
         B, L, d1 = x.shape
         d2 = gc.shape[-1]
         rows, K, V = B * L, d1 + d2, w.shape[0]
-        xb = ops.bf16_zeros(rows, K, dev)
+        xb = SCRATCH.bf16(rows, K, dev)
         ld = xb.shape[1]
         ops.cast_bf16(x.contiguous(), d1, xb, ld, rows, d1)
         ops.cast_bf16(gc.contiguous(), d2, xb, ld, rows, d2, y_off=d1)
@@ -619,7 +687,7 @@ class WorkerHeadFn(torch.autograd.Function):
         dev = dlogp.device
         rows, K = B * L, d1 + d2
         need = ctx.needs_input_grad
-        gb = ops.bf16_zeros(rows, V, dev)
+        gb = SCRATCH.bf16(rows, V, dev)
         ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
         wb = SHADOWS.weight(w)
         dcat = torch.empty(rows, K, device=dev) if (need[0] or need[1]) else None
@@ -650,7 +718,7 @@ class PosEncFn(torch.autograd.Function):
         B, S, D, p_drop, seed, has_b = ctx.cfg
         g = dout
         if p_drop > 0:
-            tmp = ops.bf16_zeros(B * S, D, dout.device)
+            tmp = SCRATCH.bf16(B * S, D, dout.device)
             ops.cast_bf16(dout.contiguous(), D, tmp, tmp.shape[1], B * S, D, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
             g = tmp[:, :D].float().view(B, S, D)
         return g, (g if has_b else None), None, None

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, synthetic as syn
-from .functional import SEEDS, SHADOWS
+from .functional import SCRATCH, SEEDS, SHADOWS
 from .loss.biased_kl import BiasedKL
 from .loss.label_smoothing import LabelSmoothing
 from .model.bm_hrl_agent import BMHrlAgent, BMWorkerValueFunction
@@ -151,10 +151,12 @@ class CaptionTrainer:
         """zero_grad -> forward -> loss -> backward -> (all-reduce) -> Adam.  Returns the loss (device scalar)."""
         trg_in, trg_y = captions[:, :-1].contiguous(), captions[:, 1:].contiguous()
         self.opt.zero_grad()
+        SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
         loss, _ = self._forward_loss(fs, trg_in, trg_y, rl)
         loss.backward()
         self.opt.gather_grads()
+        SCRATCH.end_step()
         scale = self.opt.all_reduce()
         self.opt.step(scale)
         return loss.detach()
@@ -192,11 +194,13 @@ class CaptionTrainer:
         cap = st["captions"]
         trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
         self.opt.zero_grad()
+        SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
         SHADOWS.invalidate()
         loss, _ = self._forward_loss(st, trg_in, trg_y)
         loss.backward()
         self.opt.gather_grads()
+        SCRATCH.end_step()
         self.static_loss.copy_(loss.detach())
 
     def _graph_body_b(self, scale):
