@@ -44,6 +44,7 @@ PROTOTYPES = {
     "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
     "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr],
+    "bmhrl_cast_segments": [ptr, i32, i32, ptr],
     "bmhrl_colsum_bf16": [ptr, i64, ptr, i32, i64, i32, ptr],
     "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_gate_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],

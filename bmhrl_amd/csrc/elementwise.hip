@@ -164,6 +164,44 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* 
   }
 }
 
+// Many (rows, cols) fp32 matrices -> bf16 (padded leading dimension) or fp32 copies, ONE launch: the per-step refresh
+// of all bf16 weight shadows and concatenated biases.  seg = 6 int64 per segment: source address, destination address,
+// rows, cols, destination leading dimension (elements; <= 0: the destination is fp32, tightly packed), first block.
+// A block owns 4096 consecutive elements of one segment and finds it by bisection over the first-block column.
+constexpr int SEG_WORDS = 6, SEG_ELEMS_PER_BLOCK = 4096;
+__global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid * SEG_WORDS + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* e = seg + lo * SEG_WORDS;
+  const float* __restrict__ src = reinterpret_cast<const float*>(e[0]);
+  const long rows = e[2], cols = e[3], ldd = e[4];
+  const long total = rows * cols;
+  const long base = ((long)blockIdx.x - e[5]) * SEG_ELEMS_PER_BLOCK;
+  if (ldd <= 0) {
+    float* __restrict__ dst = reinterpret_cast<float*>(e[1]);
+    for (long i = base + threadIdx.x; i < base + SEG_ELEMS_PER_BLOCK && i < total; i += blockDim.x) dst[i] = src[i];
+    return;
+  }
+  bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(e[1]);
+  if ((cols & 3) == 0 && (ldd & 3) == 0 && ((e[0] | e[1]) & 15) == 0) {      // 16-byte loads, 8-byte stores
+    for (long i = base + 4 * threadIdx.x; i < base + SEG_ELEMS_PER_BLOCK && i < total; i += 4 * blockDim.x) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+      const long r = i / cols, c = i - r * cols;
+      bf16x4 o;
+      o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+      *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = o;
+    }
+  } else {
+    for (long i = base + threadIdx.x; i < base + SEG_ELEMS_PER_BLOCK && i < total; i += blockDim.x) {
+      const long r = i / cols, c = i - r * cols;
+      dst[r * ldd + c] = (bf16_t)src[i];
+    }
+  }
+}
+
 // db[n] (+)= sum_m dY[m][n]: a block covers 512 columns x `rows_per_block` rows; thread = (column group of 8 bf16 =
 // one 16-byte load, row lane 0..3); grid.y splits the rows; one atomic per column per block.
 __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ld, float* __restrict__ db, long rows, int cols,
@@ -359,6 +397,12 @@ extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy
   BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y,
                      (long)ldy, (long)rows, cols, scale, dropout_p, seed, seed_dev);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_cast_segments(const int64_t* segments, int32_t n_segments, int32_t n_blocks, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(segments && n_segments > 0 && n_blocks > 0);
+  hipLaunchKernelGGL(cast_segments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, S_(stream), segments, n_segments);
   return hip_status(hipGetLastError());
 }
 

@@ -71,6 +71,43 @@ class ShadowCache:
         return buf
 
 
+    # ---- whole-cache refresh in one launch (training steps: every weight changes every step)
+    def refresh(self):
+        """Re-cast every cached weight shadow and concatenated bias with ONE kernel launch and mark the entries
+        current, so the lookups of the following forward / backward are hits.  The segment table is rebuilt only when
+        the set of cached entries changed (the first step of a model populates the cache through the per-weight path)."""
+        live = [(k, e, 1) for k, e in self.w.items() if all(r() is not None for r in e[2])] + \
+               [(k, e, 0) for k, e in self.b.items() if all(r() is not None for r in e[2])]
+        live = [(k, e, kind) for k, e, kind in live if e[1].is_cuda]
+        if not live:
+            return
+        sig = tuple((k, kind, e[1].data_ptr()) + tuple(r().data_ptr() for r in e[2]) for k, e, kind in live)
+        if getattr(self, "_plan_sig", None) != sig:
+            rows_, blk = [], 0
+            for k, e, kind in live:
+                buf, off = e[1], 0
+                for r in e[2]:
+                    p = r()
+                    if kind:      # weight: (N_p, K) fp32 -> rows [off, off + N_p) of the (N, ld) bf16 shadow
+                        n, kk, ld = p.shape[0], p.shape[1], buf.shape[1]
+                        rows_.append([p.data_ptr(), buf.data_ptr() + 2 * off * ld, n, kk, ld, blk])
+                        off += n
+                        blk += (n * kk + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
+                    else:         # bias: fp32 copy into the concatenated vector
+                        n = p.numel()
+                        rows_.append([p.data_ptr(), buf.data_ptr() + 4 * off, 1, n, 0, blk])
+                        off += n
+                        blk += (n + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
+            dev = live[0][1][1].device
+            self._plan = (torch.tensor(rows_, dtype=torch.int64).to(dev), len(rows_), blk)
+            self._plan_sig = sig
+        table, n_seg, n_blk = self._plan
+        ops.cast_segments(table, n_seg, n_blk)
+        for k, e, kind in live:
+            params = tuple(r() for r in e[2])
+            (self.w if kind else self.b)[k] = (self._version(params), e[1], e[2])
+
+
 SHADOWS = ShadowCache()
 
 

@@ -118,6 +118,15 @@ def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_of
                                            seed, _p(seed_dev), stream()), "bmhrl_cast_bf16")
 
 
+SEG_ELEMS_PER_BLOCK = 4096
+
+
+def cast_segments(table: torch.Tensor, n_segments: int, n_blocks: int):
+    """table: int64 (n_segments, 6) on the device -- see bmhrl_cast_segments in include/bmhrl_hip.h"""
+    _need_cuda(table)
+    _lib.check(_lib.load().bmhrl_cast_segments(table.data_ptr(), n_segments, n_blocks, stream()), "bmhrl_cast_segments")
+
+
 def colsum_bf16(dY, ld, db, accumulate, rows, cols, dy_off=0, db_off=0):
     _lib.check(_lib.load().bmhrl_colsum_bf16(dY.data_ptr() + 2 * dy_off, ld, db.data_ptr() + 4 * db_off, int(accumulate),
                                              rows, cols, stream()), "bmhrl_colsum_bf16")

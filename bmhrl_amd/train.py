@@ -153,6 +153,7 @@ class CaptionTrainer:
         self.opt.zero_grad()
         SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
+        SHADOWS.refresh()
         loss, _ = self._forward_loss(fs, trg_in, trg_y, rl)
         loss.backward()
         self.opt.gather_grads()
@@ -175,6 +176,8 @@ class CaptionTrainer:
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._graph_body_a()
                 self._graph_body_b(1.0)
+            SHADOWS.refresh()                 # builds the segment table of the one-launch shadow refresh (a host -> device
+                                              # copy, not allowed while capturing); the captured body reuses it
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
@@ -197,6 +200,7 @@ class CaptionTrainer:
         SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
         SHADOWS.invalidate()
+        SHADOWS.refresh()
         loss, _ = self._forward_loss(st, trg_in, trg_y)
         loss.backward()
         self.opt.gather_grads()

@@ -124,6 +124,14 @@ int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const fl
 int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
                     float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
 
+/* One launch for many casts: the per-step refresh of every bf16 weight shadow / concatenated bias (what the reference
+ * gets for free by computing in fp32: model/multihead_attention.py:53-56, model/blocks.py:181-182 hold fp32 weights).
+ * `segments` (device memory) holds 6 int64 per segment: source address (fp32), destination address, rows, cols,
+ * destination leading dimension in elements (bf16 destination) or <= 0 (fp32 destination, packed), and the index of the
+ * segment's first block; a block covers 4096 consecutive elements, n_blocks = sum over segments of
+ * ceil(rows*cols / 4096). */
+int bmhrl_cast_segments(const int64_t* segments, int32_t n_segments, int32_t n_blocks, bmhrl_stream_t stream);
+
 /* db[n] (+)= sum_m dY[m][n]  (bias gradient of nn.Linear), dY bf16 */
 int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t accumulate, int64_t rows, int32_t cols,
                       bmhrl_stream_t stream);
