@@ -277,6 +277,46 @@ __global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg)
   }
 }
 
+// y = bf16(x * scale * dropout) AND colsum[n] += sum_m y[m][n] in one pass (dY cast + bias gradient of the same layer).
+// Block = 256 columns x `rows_per_block` rows; thread = (4-column group, row lane 0..3); one atomic per column per block.
+__global__ void cast_colsum_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows, int cols,
+                                   float scale, float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev,
+                                   float* __restrict__ colsum, int rows_per_block) {
+  __shared__ float red[4][256];
+  const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
+  const int cg = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + cg * 4;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const bool vec = (ldx & 3) == 0 && (ldy & 3) == 0 && col + 4 <= cols && (((uintptr_t)x & 15) | ((uintptr_t)y & 7)) == 0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < cols) {
+    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += 4) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(x + r * ldx + col);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+        for (int j = 0; j < 4 && col + j < cols; ++j) v[j] = x[r * ldx + col + j];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float w = v[j] * scale;
+        if (p > 0.f && col + j < cols) w *= dropout_scale(p, seed, (uint64_t)r * cols + col + j);
+        o[j] = (bf16_t)w;
+        acc[j] += (float)o[j];
+      }
+      if (vec) *reinterpret_cast<bf16x4*>(y + r * ldy + col) = o;
+      else for (int j = 0; j < 4 && col + j < cols; ++j) y[r * ldy + col + j] = o[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[ry][cg * 4 + j] = acc[j];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) atomicAdd(colsum + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // db[n] (+)= sum_m dY[m][n]: a block covers 512 columns x `rows_per_block` rows; thread = (column group of 8 bf16 =
 // one 16-byte load, row lane 0..3); grid.y splits the rows; one atomic per column per block.
 __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ld, float* __restrict__ db, long rows, int cols,
@@ -491,6 +531,19 @@ extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy
   return hip_status(hipGetLastError());
 }
 
+extern "C" int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
+                                      float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* colsum,
+                                      bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && y && colsum && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
+  const int col_blocks = (cols + 255) / 256;
+  int rpb = (int)((rows * col_blocks + 511) / 512);      // aim at ~512 blocks in total
+  if (rpb < 16) rpb = 16;
+  dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  hipLaunchKernelGGL(cast_colsum_kernel, grid, block, 0, S_(stream), x, (long)ldx, (bf16_t*)y, (long)ldy, (long)rows, cols,
+                     scale, dropout_p, seed, seed_dev, colsum, rpb);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" int bmhrl_cast_segments(const int64_t* segments, int32_t n_segments, int32_t n_blocks, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(segments && n_segments > 0 && n_blocks > 0);
   hipLaunchKernelGGL(cast_segments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, S_(stream), segments, n_segments);
@@ -566,4 +619,4 @@ extern "C" int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, 
 }
 
 extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
-extern "C" int bmhrl_hip_abi_version(void) { return 1; }
+extern "C" int bmhrl_hip_abi_version(void) { return 2; }   // 2: bmhrl_gemm_desc.colsum, bmhrl_cast_colsum_bf16, bmhrl_cast_segments

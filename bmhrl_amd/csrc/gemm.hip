@@ -31,6 +31,7 @@ struct GemmArgs {
   const float* rowvec; const float* rowvec2; long rv_sb1, rv_sb2;
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
+  float* colsum; long cs_sb2;
   int tiles_m, splits, k_per_split, vec_ok, dbg;
 };
 
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   };
 
   constexpr int GROUPS = BM * BN / 4 / 256;
+  // optional column sums of the OUTPUT tile (the bias gradient of the layer whose dY this GEMM produces): a thread
+  // always works on the same 4 columns (256 % (BN/4) == 0), so it keeps a private partial and the 256 / (BN/4) threads
+  // sharing a column group are combined through LDS: one atomic per column per tile
+  float* __restrict__ CSg = p.colsum ? p.colsum + b2 * p.cs_sb2 : nullptr;
+  f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
   auto run = [&](auto kind) {
 #pragma unroll 4
     for (int i = 0; i < GROUPS; ++i) {
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j);
+          cs4 += o;
           if (Cg) {
             float* dst = Cg + (long)m * p.ldc + n;
             if (p.splits > 1) {
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             const float r = Rg ? Rg[(long)m * p.ldr + n + j] : 0.f;
             const float ax = AUXg ? (float)AUXg[(long)m * p.ldaux + n + j] : 0.f;
             const float o = elem(kind, a4[j], b, r, ax, rv, rv2, m, n + j);
+            cs4[j] += o;
             if (Cg) {
               float* dst = Cg + (long)m * p.ldc + n + j;
               if (p.splits > 1) atomicAdd(dst, o);
@@ -319,6 +327,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   } else if (p.epilogue == BMHRL_EPI_PROB) run(std::integral_constant<int, 2>{});
   else if (p.epilogue == BMHRL_EPI_DSCORE) run(std::integral_constant<int, 3>{});
   else run(std::integral_constant<int, 4>{});
+  if (CSg) {
+    constexpr int CG = BN / 4, SHARE = 256 / CG;        // column groups per tile, threads per group
+    __syncthreads();                                    // everyone is done reading the staged accumulators
+    *reinterpret_cast<f32x4*>(sC + (tid / CG) * BN + (tid % CG) * 4) = cs4;
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < SHARE; ++k) t += sC[k * BN + tid];
+      atomicAdd(CSg + n0 + tid, t);
+    }
+  }
 }
 
 template <int TM, int TN>
@@ -368,6 +388,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.aux = (const bf16_t*)d->aux; a.ldaux = d->ldaux; a.aux_sb1 = d->aux_sb1; a.aux_sb2 = d->aux_sb2;
   a.dropout_p = d->dropout_p; a.seed = d->seed; a.seed_dev = d->seed_dev; a.tiles_m = 0;
   a.drop_sb1 = d->drop_sb1; a.drop_sb2 = d->drop_sb2; a.drop_sm = d->drop_sm;
+  a.colsum = d->colsum; a.cs_sb2 = d->colsum_sb2;
   if (a.drop_sb1 == 0 && a.drop_sb2 == 0 && a.drop_sm == 0) {
     a.drop_sm = d->N; a.drop_sb2 = (long)d->M * d->N; a.drop_sb1 = a.drop_sb2 * d->batch2;
   }
@@ -384,7 +405,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   // gradients dW = dY^T X.  Only plain fp32 outputs qualify and the caller must opt in (C zero-initialised).
   int splits = 1;
   const bool can_split = d->allow_split_k && d->C && !d->Cb && d->epilogue == BMHRL_EPI_LINEAR && !d->relu && !d->mask &&
-                         d->dropout_p == 0.f && !d->accumulate;
+                         d->dropout_p == 0.f && !d->accumulate && !d->colsum;
   static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
   static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
   bool big = force_tile ? force_tile == 2 : big_tiles >= big_min;

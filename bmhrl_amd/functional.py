@@ -240,9 +240,13 @@ def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, ms
 
 
 def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, dQb, dq_off, lddq, dKb, dk_off, lddk,
-                   dVb, dv_off, lddv, mask, msb, msq, B, H, Sq, Sk, dk, p_drop):
+                   dVb, dv_off, lddv, mask, msb, msq, B, H, Sq, Sk, dk, p_drop, db_q=None, db_k=None, db_v=None):
     """dOb: gradient w.r.t. the PRE-dropout attention output (bf16 [B*Sq, D]); Ob: saved post-dropout output.
-    Writes bf16 dQ/dK/dV into column slices of the given buffers."""
+    Writes bf16 dQ/dK/dV into column slices of the given buffers.  db_* = (zeroed fp32 tensor, offset): the column sums
+    of dQ / dK / dV (bias gradients of the three projections) are accumulated there by the producing GEMM's epilogue."""
+    csq = dict(colsum=db_q[0], colsum_off=db_q[1], colsum_sb2=dk) if db_q is not None else {}
+    csk = dict(colsum=db_k[0], colsum_off=db_k[1], colsum_sb2=dk) if db_k is not None else {}
+    csv = dict(colsum=db_v[0], colsum_off=db_v[1], colsum_sb2=dk) if db_v is not None else {}
     dev = dOb.device
     D = H * dk
     scale = 1.0 / math.sqrt(dk)
@@ -264,17 +268,17 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
              rowvec=delta, rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=pstr)
     # dV = P^T dO ; dK = dS^T Q ; dQ = dS K
     ops.gemm(P, dOb, Sk, dk, Sq, lda=Skp, ldb=D, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,
-             b_strides=(Sq * D, dk), C_bf16=dVb, ldcb=lddv, cb_off=dv_off, cb_strides=(Sk * lddv, dk))
+             b_strides=(Sq * D, dk), C_bf16=dVb, ldcb=lddv, cb_off=dv_off, cb_strides=(Sk * lddv, dk), **csv)
     ops.gemm(dS, Qb, Sk, dk, Sq, lda=Skp, ldb=ldq, b_off=q_off, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,
-             b_strides=(Sq * ldq, dk), C_bf16=dKb, ldcb=lddk, cb_off=dk_off, cb_strides=(Sk * lddk, dk))
+             b_strides=(Sq * ldq, dk), C_bf16=dKb, ldcb=lddk, cb_off=dk_off, cb_strides=(Sk * lddk, dk), **csk)
     ops.gemm(dS, Kb, Sq, dk, Sk, lda=Skp, ldb=ldk, b_off=k_off, b_trans=True, batch=(B, H), a_strides=pstr,
-             b_strides=(Sk * ldk, dk), C_bf16=dQb, ldcb=lddq, cb_off=dq_off, cb_strides=(Sq * lddq, dk))
+             b_strides=(Sk * ldk, dk), C_bf16=dQb, ldcb=lddq, cb_off=dq_off, cb_strides=(Sq * lddq, dk), **csq)
 
 
 # ------------------------------------------------------------------------------------------------ linear helpers
 def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx, dx_f32=None, dx_bf16=None, lddxb=0,
                 dx_epilogue=ops.EPI_LINEAR, dx_alpha=1.0, dx_aux=None, ldaux=0, dx_drop=0.0, dx_seed=0,
-                dy_off=0, x_off=0, w_off=0, dx_accumulate=False):
+                dy_off=0, x_off=0, w_off=0, dx_accumulate=False, dx_colsum=None):
     """Gradients of y = x W^T + b given dy (bf16 [rows, N] at dy_off, leading dim ldy).
     dW (fp32 [N, K]) = dy^T x ; db = column sums of dy ; dx = dy W (fp32 and/or bf16, optional fused epilogue)."""
     dev = dyb.device
@@ -289,8 +293,21 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
     if need_dx:
         ops.gemm(dyb, wb, rows, K, N, lda=ldy, ldb=wb.shape[1], a_off=dy_off, b_off=w_off, b_trans=True, C_f32=dx_f32,
                  ldc=K, C_bf16=dx_bf16, ldcb=lddxb, epilogue=dx_epilogue, alpha=dx_alpha, aux=dx_aux, ldaux=ldaux,
-                 dropout_p=dx_drop, seed=dx_seed, seed_dev=SEEDS.dev, accumulate=dx_accumulate)
+                 dropout_p=dx_drop, seed=dx_seed, seed_dev=SEEDS.dev, accumulate=dx_accumulate, colsum=dx_colsum)
     return dw, db
+
+
+def _cast_dy(dy, rows, N, p_drop, seed, want_db):
+    """bf16 copy of an incoming fp32 gradient (through the layer's output dropout) and, when the bias needs one, its
+    column sums from the same pass.  Returns (dyb, db or None)."""
+    dev = dy.device
+    dyb = SCRATCH.bf16(rows, N, dev)
+    if want_db:
+        db = SCRATCH.f32(N, device=dev)
+        ops.cast_colsum_bf16(dy, N, dyb, dyb.shape[1], rows, N, db, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+        return dyb, db
+    ops.cast_bf16(dy, N, dyb, dyb.shape[1], rows, N, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+    return dyb, None
 
 
 class MHAFn(torch.autograd.Function):
@@ -373,13 +390,12 @@ class MHAFn(torch.autograd.Function):
         dy = dy.contiguous()
         keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         # d(out) through the residual-branch dropout -> bf16
-        dyb = SCRATCH.bf16(rows_q, dq, dev)
-        ops.cast_bf16(dy, dq, dyb, ldx, rows_q, dq, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        dyb, dbo = _cast_dy(dy, rows_q, dq, p_drop, s_res, need[11])
         # linear_d2Q backward; its dx is d(attention output), taken back through the output dropout in the epilogue
         dOb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
         w_o = SHADOWS.weight(wo)
-        dwo, dbo = _linear_bwd(dyb, ldx, rows_q, dq, Ob, D, D, w_o, need_dw=need[10], need_db=need[11], need_dx=True,
-                               dx_bf16=dOb, lddxb=D, dx_drop=p_drop, dx_seed=s_attn)
+        dwo, _ = _linear_bwd(dyb, ldx, rows_q, dq, Ob, D, D, w_o, need_dw=need[10], need_db=False, need_dx=True,
+                             dx_bf16=dOb, lddxb=D, dx_drop=p_drop, dx_seed=s_attn)
         del keep
         if self_att:
             dQKV = torch.empty(rows_q, 3 * D, dtype=_BF16, device=dev)
@@ -390,16 +406,30 @@ class MHAFn(torch.autograd.Function):
             dKV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
             dKb = dVb = dKV
             lddq, lddk = D, 2 * D
+        # bias gradients of the Q / K / V projections = column sums of dQ / dK / dV: taken in the epilogues of the GEMMs
+        # that produce them (layout [q | k | v] for self attention, [q], [k | v] for cross attention)
+        need_bq, need_bkv = need[5], need[7] or need[9]
+        if self_att:
+            db_all = SCRATCH.f32(3 * D, device=dev) if (need_bq or need_bkv) else None
+            tq = tk = tv = None
+            if db_all is not None:
+                tq, tk, tv = (db_all, 0), (db_all, D), (db_all, 2 * D)
+        else:
+            db_qq = SCRATCH.f32(D, device=dev) if need_bq else None
+            db_kv = SCRATCH.f32(2 * D, device=dev) if need_bkv else None
+            tq = (db_qq, 0) if need_bq else None
+            tk = (db_kv, 0) if need_bkv else None
+            tv = (db_kv, D) if need_bkv else None
         _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldk, dQb, q_off, lddq, dKb, k_off, lddk,
-                       dVb, v_off, lddk, m8, msb, msq, B, H, Sq, Sk, dk, p_drop)
+                       dVb, v_off, lddk, m8, msb, msq, B, H, Sq, Sk, dk, p_drop, db_q=tq, db_k=tk, db_v=tv)
         dxn = torch.empty(rows_q, dq, device=dev) if (need[0] or (has_ln and (need[2] or need[3]))) else None
         dwq = dbq = dwk = dbk = dwv = dbv = dkv_in = None
         if self_att:
             w_qkv = SHADOWS.weight(wq, wk, wv)
             need_w = need[4] or need[6] or need[8]
-            need_b = need[5] or need[7] or need[9]
-            dw, db = _linear_bwd(dQKV, 3 * D, rows_q, 3 * D, xb, ldx, dq, w_qkv, need_dw=need_w, need_db=need_b,
-                                 need_dx=dxn is not None, dx_f32=dxn)
+            dw, _ = _linear_bwd(dQKV, 3 * D, rows_q, 3 * D, xb, ldx, dq, w_qkv, need_dw=need_w, need_db=False,
+                                need_dx=dxn is not None, dx_f32=dxn)
+            db = db_all
             if dw is not None:
                 dwq, dwk, dwv = dw[:D], dw[D:2 * D], dw[2 * D:]
             if db is not None:
@@ -407,12 +437,14 @@ class MHAFn(torch.autograd.Function):
         else:
             w_q = SHADOWS.weight(wq)
             w_kv = SHADOWS.weight(wk, wv)
-            dwq, dbq = _linear_bwd(dQb, D, rows_q, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=need[5],
-                                   need_dx=dxn is not None, dx_f32=dxn)
+            dwq, _ = _linear_bwd(dQb, D, rows_q, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=False,
+                                 need_dx=dxn is not None, dx_f32=dxn)
+            dbq = db_qq
             if need[1]:
                 dkv_in = torch.empty(B, Sk, dkv, device=dev)
-            dw, db = _linear_bwd(dKV, 2 * D, rows_k, 2 * D, kvb, kvb.shape[1], dkv, w_kv, need_dw=need[6] or need[8],
-                                 need_db=need[7] or need[9], need_dx=need[1], dx_f32=dkv_in)
+            dw, _ = _linear_bwd(dKV, 2 * D, rows_k, 2 * D, kvb, kvb.shape[1], dkv, w_kv, need_dw=need[6] or need[8],
+                                need_db=False, need_dx=need[1], dx_f32=dkv_in)
+            db = db_kv
             if dw is not None:
                 dwk, dwv = dw[:D], dw[D:]
             if db is not None:
@@ -514,18 +546,18 @@ class FFNFn(torch.autograd.Function):
         ldx = pad8(d)
         need = ctx.needs_input_grad
         dy = dy.contiguous()
-        dyb = SCRATCH.bf16(rows, d, dev)
-        ops.cast_bf16(dy, d, dyb, ldx, rows, d, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        dyb, db2 = _cast_dy(dy, rows, d, p_drop, s_res, need[6])
         wb1, wb2 = SHADOWS.weight(w1), SHADOWS.weight(w2)
         # dz = (dy W2) * [h > 0] / (1-p): h already carries relu and the inner dropout mask
         dzb = SCRATCH.bf16(rows, dff, dev)
         keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
-        dw2, db2 = _linear_bwd(dyb, ldx, rows, d, hb, hb.shape[1], dff, wb2, need_dw=need[5], need_db=need[6], need_dx=True,
-                               dx_bf16=dzb, lddxb=dzb.shape[1], dx_epilogue=ops.EPI_RELU_BWD, dx_alpha=keep, dx_aux=hb,
-                               ldaux=hb.shape[1])
+        db1 = SCRATCH.f32(dff, device=dev) if need[4] else None     # column sums of dz, from the epilogue that writes dz
+        dw2, _ = _linear_bwd(dyb, ldx, rows, d, hb, hb.shape[1], dff, wb2, need_dw=need[5], need_db=False, need_dx=True,
+                             dx_bf16=dzb, lddxb=dzb.shape[1], dx_epilogue=ops.EPI_RELU_BWD, dx_alpha=keep, dx_aux=hb,
+                             ldaux=hb.shape[1], dx_colsum=db1)
         dxn = torch.empty(rows, d, device=dev)
-        dw1, db1 = _linear_bwd(dzb, dzb.shape[1], rows, dff, xb, ldx, d, wb1, need_dw=need[3], need_db=need[4], need_dx=True,
-                               dx_f32=dxn)
+        dw1, _ = _linear_bwd(dzb, dzb.shape[1], rows, dff, xb, ldx, d, wb1, need_dw=need[3], need_db=False, need_dx=True,
+                             dx_f32=dxn)
         dx = torch.empty(B, S, d, device=dev)
         dlnw = SCRATCH.f32(d, device=dev) if need[1] else None
         dlnb = SCRATCH.f32(d, device=dev) if need[2] else None
@@ -569,13 +601,12 @@ class LinearFn(torch.autograd.Function):
             dy2 = torch.where(y != 0, dy2 * keep, torch.zeros_like(dy2)) if relu else None
             if dy2 is None:
                 dy2 = dy.contiguous().view(rows, N)
-        dyb = SCRATCH.bf16(rows, N, dev)
         drop = p_drop if not relu else 0.0
-        ops.cast_bf16(dy2, N, dyb, dyb.shape[1], rows, N, dropout_p=drop, seed=seed, seed_dev=SEEDS.dev)
+        dyb, db = _cast_dy(dy2, rows, N, drop, seed, has_b and need[2])
         wb = SHADOWS.weight(w)
         dx = torch.empty(rows, K, device=dev) if need[0] else None
-        dw, db = _linear_bwd(dyb, dyb.shape[1], rows, N, xb, xb.shape[1], K, wb, need_dw=need[1], need_db=has_b and need[2],
-                             need_dx=need[0], dx_f32=dx)
+        dw, _ = _linear_bwd(dyb, dyb.shape[1], rows, N, xb, xb.shape[1], K, wb, need_dw=need[1], need_db=False,
+                            need_dx=need[0], dx_f32=dx)
         return (dx.view(shp) if dx is not None else None), dw, db, None, None
 
 

@@ -43,7 +43,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          C_bf16: Optional[torch.Tensor] = None, ldcb=0, cb_strides=(0, 0), cb_off=0,
          epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
-         aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False) -> None:
+         aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False,
+         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0) -> None:
     """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
     _need_cuda(A, B, C_f32, C_bf16)
     d = _lib.GemmDesc()
@@ -62,6 +63,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.aux = None if aux is None else aux.data_ptr() + 2 * aux_off; d.ldaux = ldaux; d.aux_sb1, d.aux_sb2 = aux_strides
     d.dropout_p = dropout_p; d.seed = seed; d.seed_dev = _p(seed_dev)
     d.drop_sb1, d.drop_sb2, d.drop_sm = drop_strides
+    d.colsum = None if colsum is None else colsum.data_ptr() + 4 * colsum_off; d.colsum_sb2 = colsum_sb2
     _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
 
 
@@ -116,6 +118,14 @@ def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_of
     _need_cuda(x, y)
     _lib.check(_lib.load().bmhrl_cast_bf16(x.data_ptr(), ldx, y.data_ptr() + 2 * y_off, ldy, rows, cols, scale, dropout_p,
                                            seed, _p(seed_dev), stream()), "bmhrl_cast_bf16")
+
+
+def cast_colsum_bf16(x, ldx, y, ldy, rows, cols, colsum, scale=1.0, dropout_p=0.0, seed=0, seed_dev=None, colsum_off=0):
+    """y = bf16(x * scale * dropout); colsum[colsum_off + n] += column sums of y (colsum must start zeroed)"""
+    _need_cuda(x, y, colsum)
+    _lib.check(_lib.load().bmhrl_cast_colsum_bf16(x.data_ptr(), ldx, y.data_ptr(), ldy, rows, cols, scale, dropout_p, seed,
+                                                  _p(seed_dev), colsum.data_ptr() + 4 * colsum_off, stream()),
+               "bmhrl_cast_colsum_bf16")
 
 
 SEG_ELEMS_PER_BLOCK = 4096

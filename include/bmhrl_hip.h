@@ -60,6 +60,8 @@ typedef struct bmhrl_gemm_desc {
   float dropout_p; uint64_t seed;                 /* inverted dropout on v; element id = b1*drop_sb1 + b2*drop_sb2 + m*drop_sm + n */
   int64_t drop_sb1, drop_sb2, drop_sm;            /* (all 0 -> id = (batch*M + m)*N + n) */
   const uint64_t* seed_dev;                       /* optional device word added to seed (changes under graph replay) */
+  float* colsum; int64_t colsum_sb2;              /* optional: colsum[b2*colsum_sb2 + n] += sum_m v (fp32 atomics; the bias
+                                                     gradient of the layer whose dY this GEMM writes); not with split-K */
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
@@ -123,6 +125,12 @@ int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const fl
  * and inverted dropout (regenerates the forward mask from seed: element id = row*cols + col). */
 int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
                     float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
+
+/* bmhrl_cast_bf16 + column sums of the rounded result in one pass: colsum[n] += sum_m y[m][n] (fp32 atomics; colsum is
+ * accumulated into, the caller zeroes it).  dY cast and bias gradient of one layer -- nn.Linear's db of
+ * model/multihead_attention.py:53-56 / model/blocks.py:181-182 under autograd. */
+int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
+                           float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* colsum, bmhrl_stream_t stream);
 
 /* One launch for many casts: the per-step refresh of every bf16 weight shadow / concatenated bias (what the reference
  * gets for free by computing in fp32: model/multihead_attention.py:53-56, model/blocks.py:181-182 hold fp32 weights).

@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/bmhrl_hip.h but not exported"
     assert set(_lib.PROTOTYPES) | {"bmhrl_hip_arch", "bmhrl_hip_abi_version"} == set(syms)
     assert lib.bmhrl_hip_arch() == b"gfx950"
-    assert lib.bmhrl_hip_abi_version() == 1
+    assert lib.bmhrl_hip_abi_version() == 2
 
 
 def test_ops_refuse_cpu_tensors():

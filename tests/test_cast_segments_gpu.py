@@ -53,3 +53,31 @@ def test_shadow_refresh_tracks_weight_updates():
     assert w1.data_ptr() == w0.data_ptr() and b1.data_ptr() == b0.data_ptr()        # same buffers, no re-allocation
     assert torch.equal(w1[:, :300], torch.cat([p.detach() for p in ws]).to(torch.bfloat16))
     assert torch.equal(b1, torch.cat([p.detach() for p in bs]))
+
+
+def test_cast_colsum_and_gemm_epilogue_colsum():
+    """Bias gradients taken in the producing kernels: cast + column sums, and column sums of a GEMM's output tile."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    for rows, cols in ((480, 300), (4096, 1024), (37, 5)):
+        x = torch.randn(rows, cols, generator=g).to(dev)
+        y = torch.zeros(rows, ops.pad8(cols), dtype=torch.bfloat16, device=dev)
+        cs = torch.zeros(cols, device=dev)
+        ops.cast_colsum_bf16(x, cols, y, y.shape[1], rows, cols, cs, scale=0.5)
+        ref = (x * 0.5).to(torch.bfloat16)
+        assert torch.equal(y[:, :cols], ref)
+        assert float((cs - ref.float().sum(0)).abs().max()) < 1e-3 * max(1.0, float(ref.float().sum(0).abs().max()))
+    # GEMM with a bf16 output and column sums, batched over heads (column index = head * dk + n)
+    B, H, M, N, K = 2, 3, 200, 64, 96
+    A = torch.randn(B, H, M, K, generator=g).to(dev).to(torch.bfloat16)
+    Bm = torch.randn(B, H, N, K, generator=g).to(dev).to(torch.bfloat16)
+    out = torch.zeros(B * M, H * N, dtype=torch.bfloat16, device=dev)
+    cs = torch.zeros(H * N, device=dev)
+    ops.gemm(A, Bm, M, N, K, lda=K, ldb=K, batch=(B, H), a_strides=(H * M * K, M * K), b_strides=(H * N * K, N * K),
+             C_bf16=out, ldcb=H * N, cb_strides=(M * H * N, N), colsum=cs, colsum_sb2=N)
+    ref = torch.einsum("bhmk,bhnk->bmhn", A.float(), Bm.float()).reshape(B * M, H * N)
+    assert float((out.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    assert float((cs - ref.sum(0)).abs().max()) < 5e-3 * float(ref.sum(0).abs().max())
