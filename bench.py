@@ -186,7 +186,7 @@ def main():
 
     if rank == 0:
         roof = attention_roofline(dev, args.batch, cfg.rl_att_heads, args.tv, args.ta)
-        cpu = None if args.no_cpu_baseline else cpu_baseline(args)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args)   # N=1 only (bench contract)
         out = {
             "metric": "caption-train steps/sec", "value": args.steps * world / elapsed, "unit": "steps/s (one step = one "
             "B=16 batch on one GPU; whole-job aggregate over all GPUs)", "n_gpus": world, "steps": args.steps,
@@ -200,6 +200,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()      # rank 0 is still measuring the roofline kernel: keep the communicator alive until it is done
         dist.destroy_process_group()
 
 
