@@ -5,7 +5,10 @@ import torch
 from .model.masking import make_masks
 
 
-def greedy_decode(model, feature_stacks, max_len, start_idx, end_idx, pad_idx, modality, return_first=False):
+def greedy_decode(model, feature_stacks, max_len, start_idx, end_idx, pad_idx, modality, return_first=False, memoise=True):
+    """memoise=True (default) runs the encoder and the fusion layers' memory projections once per clip batch instead of
+    once per generated token; the tokens and log-probs are the same as with the reference's full re-run (memoise=False).
+    Models without encode_memory() (anything but the HIP BMHrlAgent) always take the full re-run."""
     with torch.no_grad():
         B = feature_stacks['audio'].shape[0]
         device = feature_stacks['audio'].device
@@ -13,9 +16,16 @@ def greedy_decode(model, feature_stacks, max_len, start_idx, end_idx, pad_idx, m
         trg = torch.full((B, 1), start_idx, dtype=torch.long, device=device)
         first = None
         x = ((feature_stacks['rgb'], feature_stacks['flow']), feature_stacks['audio'])
+        memoise = memoise and hasattr(model, "encode_memory") and not model.training
+        memory, kv_cache = None, {}
         while trg.size(-1) <= max_len and not bool(done.all()):
             masks = make_masks(feature_stacks, trg, modality, pad_idx)
-            preds = model.inference(x, trg, masks)
+            if memoise:
+                if memory is None:
+                    memory = model.encode_memory(x, masks)
+                preds = model.inference_from_memory(memory, trg, masks, kv_cache)
+            else:
+                preds = model.inference(x, trg, masks)
             if first is None:
                 first = preds[:, -1].clone()
             nxt = preds[:, -1].argmax(dim=-1, keepdim=True)

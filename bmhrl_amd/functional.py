@@ -319,7 +319,7 @@ class MHAFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, kv_in, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop, residual):
+    def forward(ctx, x, kv_in, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop, residual, kv_cache=None):
         dev = x.device
         B, Sq, dq = x.shape
         D = wq.shape[0]
@@ -351,16 +351,23 @@ class MHAFn(torch.autograd.Function):
         else:
             _, Sk, dkv = kv_in.shape
             rows_k = B * Sk
-            kv_in = kv_in.contiguous()
-            kvb = SCRATCH.bf16(rows_k, dkv, dev)
-            ops.cast_bf16(kv_in, dkv, kvb, kvb.shape[1], rows_k, dkv)
             w_q = SHADOWS.weight(wq)
-            w_kv = SHADOWS.weight(wk, wv)
             Qb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
-            KV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
             ops.gemm(xb, w_q, rows_q, D, dq, lda=ldx, ldb=w_q.shape[1], C_bf16=Qb, ldcb=D, bias=bq.detach())
-            ops.gemm(kvb, w_kv, rows_k, 2 * D, dkv, lda=kvb.shape[1], ldb=w_kv.shape[1], C_bf16=KV, ldcb=2 * D,
-                     bias=SHADOWS.bias(bk, bv))
+            # decoding: the memory (encoder output) and these weights do not change between the tokens of a clip, so its
+            # K|V projection is computed once per clip (`kv_cache`: a dict owned by the decoder, no-grad only)
+            KV = kv_cache.get((id(wk), id(wv))) if kv_cache is not None else None
+            kvb = None
+            if KV is None:
+                kv_in = kv_in.contiguous()
+                kvb = SCRATCH.bf16(rows_k, dkv, dev)
+                ops.cast_bf16(kv_in, dkv, kvb, kvb.shape[1], rows_k, dkv)
+                w_kv = SHADOWS.weight(wk, wv)
+                KV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
+                ops.gemm(kvb, w_kv, rows_k, 2 * D, dkv, lda=kvb.shape[1], ldb=w_kv.shape[1], C_bf16=KV, ldcb=2 * D,
+                         bias=SHADOWS.bias(bk, bv))
+                if kv_cache is not None:
+                    kv_cache[(id(wk), id(wv))] = KV
             Kb = Vb = KV
             q_off, k_off, v_off, ldq, ldk = 0, 0, D, D, 2 * D
         Ob, stats = _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldk, m8, msb, msq, B, H, Sq, Sk, dk, p_drop, s_attn)
@@ -460,7 +467,7 @@ class MHAFn(torch.autograd.Function):
             dx = dxn.view(B, Sq, dq)
             if residual:
                 dx = dx + dy
-        return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None)
+        return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None, None)
 
 
 class AttnCoreFn(torch.autograd.Function):

@@ -99,9 +99,10 @@ class BMFusionLayer(nn.Module):
     def forward(self, x, masks):
         C, memory = x
         Av, Va = memory
+        kvc = masks.get('_kv_cache')        # decoding only: per-clip cache of the memory K|V projections (decode.py)
         C = self.self_att.fused(C, None, masks['C_mask'], self.res_layer_self_att.norm, residual=True)
-        Ca = self.enc_att_A.fused(C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, residual=True)
-        Cv = self.enc_att_V.fused(C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, residual=True)
+        Ca = self.enc_att_A.fused(C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, residual=True, kv_cache=kvc)
+        Cv = self.enc_att_V.fused(C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, residual=True, kv_cache=kvc)
         Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
         Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
         return GateFn.apply(Cv, Ca, self.a_v_constant), memory
@@ -386,7 +387,23 @@ class BMHrlAgent(nn.Module):
         V, A = self._encode(x)
         return self.predict_with_features(emb, V, A, mask, C)
 
-    def predict_with_features(self, C_emb, V, A, mask, C=None):
+    # ---- memoised decoding.  The reference's greedy decoders re-run the whole agent -- encoder
+    # included -- for every generated token (epoch_loops/captioning_bmrl_loops.py:61-76,127-152); the encoder output and
+    # the fusion layers' K|V projections of it depend on the clip only, so they are computed once.
+    def encode_memory(self, x, mask):
+        """Encoder output (Va, Av) of a clip batch; x as in forward(), mask needs V_mask / A_mask."""
+        V, A = self._encode(x)
+        return self.bm_enc((V, A), mask)
+
+    def inference_from_memory(self, memory, trg, mask, kv_cache=None):
+        """log-probs (B, L, V) for the captions `trg` given encode_memory()'s result -- same values as inference()."""
+        emb, C = self.emb_C.embed_posenc(trg, self.pos_enc_C)
+        if kv_cache is not None:
+            mask = dict(mask)
+            mask['_kv_cache'] = kv_cache
+        return self.predict_with_features(emb, None, None, mask, C, memory=memory)[0]
+
+    def predict_with_features(self, C_emb, V, A, mask, C=None, memory=None):
         # The frozen critic only feeds the segment labels the manager needs at the very end: it runs on a side HIP
         # stream (a parallel branch of the captured graph) next to the encoder / fusion kernels.
         side = None
@@ -401,7 +418,8 @@ class BMHrlAgent(nn.Module):
             segment_labels = self._segment_labels(C_emb)
         if C is None:
             C = self.pos_enc_C(C_emb)
-        Va, Av = self.bm_enc((V, A), mask)          # Va: video stream (B,Tv,d_vid), Av: audio stream (B,Ta,d_aud)
+        # Va: video stream (B,Tv,d_vid), Av: audio stream (B,Ta,d_aud)
+        Va, Av = self.bm_enc((V, A), mask) if memory is None else memory
         if C_emb.is_cuda and self.fusion_side_stream:
             # The worker and manager fusion stacks read the same encoder output and only meet in the worker head.  Their
             # kernels work on B*L = 480 caption rows (a few workgroups each), so the two stacks run as parallel

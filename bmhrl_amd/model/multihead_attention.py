@@ -26,14 +26,16 @@ class MultiheadedAttention(nn.Module):
         return (self.linear_Q2d.weight, self.linear_Q2d.bias, self.linear_K2d.weight, self.linear_K2d.bias,
                 self.linear_V2d.weight, self.linear_V2d.bias, self.linear_d2Q.weight, self.linear_d2Q.bias)
 
-    def fused(self, x, kv, mask, norm=None, residual=False, res_dropout=None):
+    def fused(self, x, kv, mask, norm=None, residual=False, res_dropout=None, kv_cache=None):
         """[x +] drop(MHA(LN?(x), kv, kv)).  kv=None -> self attention on the normalised x.
         The reference applies dout_p twice (attention output, residual branch); both use this module's rate
         unless the residual connection's own rate is given."""
+        if kv_cache is not None and torch.is_grad_enabled():
+            raise RuntimeError("kv_cache is an inference-time cache of the memory projections: use it under torch.no_grad()")
         p = self.dout_p if self.training else 0.0
         ln_w = norm.weight if norm is not None else None
         ln_b = norm.bias if norm is not None else None
-        return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual)
+        return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual, kv_cache)
 
     def forward(self, Q, K, V, mask, causal=False):
         """Reference signature: Q (B,Sq,Dq), K (B,Sk,Dk), V (B,Sk,Dv), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).
