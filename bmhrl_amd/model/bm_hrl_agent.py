@@ -56,15 +56,43 @@ class BMEncoderLayer(nn.Module):
         self.res_layers_M1 = clone(ResidualConnection(d_model_M1, dout_p), 3)
         self.res_layers_M2 = clone(ResidualConnection(d_model_M2, dout_p), 3)
 
+    # The two modality streams of a layer are independent inside each of its three blocks (they only exchange the
+    # self-attention outputs).  On the GPU the audio half runs as a parallel branch on a second HIP stream: its K=128
+    # GEMMs are bandwidth-bound, the video half is MFMA-bound, and either alone leaves tails of idle CUs (two GEMM
+    # chains as parallel graph branches measure 11-21 % faster than back to back on MI355X, tests/bench_streams.py).
+    modality_side_stream = True
+    _side = None
+
+    def _fork(self, device):
+        cls = BMEncoderLayer
+        if cls._side is None or cls._side.device != device:
+            cls._side = torch.cuda.Stream(device=device)
+        return torch.cuda.current_stream(), cls._side
+
     def forward(self, x, masks):
         M1, M2 = x
         M1_mask, M2_mask = masks
+        if not (M1.is_cuda and self.modality_side_stream):
+            M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
+            M2 = self.self_att_M2.fused(M2, None, M2_mask, self.res_layers_M2[0].norm, residual=True)
+            M1m2 = self.bi_modal_att_M1.fused(M1, M2, M2_mask, self.res_layers_M1[1].norm, residual=True)
+            M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
+            M1m2 = self.feed_forward_M1.fused(M1m2, self.res_layers_M1[2].norm)
+            M2m1 = self.feed_forward_M2.fused(M2m1, self.res_layers_M2[2].norm)
+            return M1m2, M2m1
+        main, side = self._fork(M1.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            M2 = self.self_att_M2.fused(M2, None, M2_mask, self.res_layers_M2[0].norm, residual=True)
         M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
-        M2 = self.self_att_M2.fused(M2, None, M2_mask, self.res_layers_M2[0].norm, residual=True)
+        main.wait_stream(side)          # both self-attention outputs are needed by both cross attentions
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
+            M2m1 = self.feed_forward_M2.fused(M2m1, self.res_layers_M2[2].norm)
         M1m2 = self.bi_modal_att_M1.fused(M1, M2, M2_mask, self.res_layers_M1[1].norm, residual=True)
-        M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
         M1m2 = self.feed_forward_M1.fused(M1m2, self.res_layers_M1[2].norm)
-        M2m1 = self.feed_forward_M2.fused(M2m1, self.res_layers_M2[2].norm)
+        main.wait_stream(side)
         return M1m2, M2m1
 
 
