@@ -75,7 +75,7 @@ def attention_roofline(dev, B, H, Sq, Sk, iters=50):
         t = json.load(open(tj))
         if t["shape"] == {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}:
             traffic = t["traffic_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel<2,2> (cross-modal V<-A)", "achieved": flops / sec / 1e12,
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel (cross-modal V<-A)", "achieved": flops / sec / 1e12,
             "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0, "traffic": traffic,
             "launch_us": sec * 1e6, "flops_per_launch": flops,
             "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}}
