@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--eager", action="store_true", help="launch kernels step by step instead of replaying the HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="batch of the bounded CPU-oracle sample (default: the full B=16 step)")
     return ap.parse_args()
 
 
@@ -83,7 +83,8 @@ def attention_roofline(dev, B, H, Sq, Sk, iters=50):
 
 def cpu_baseline(args):
     """The oracle's warmstart step (forward + loss + backward + Adam) on the host cores, on a bounded sample: a batch
-    of --cpu-batch instead of B (cost is linear in B), one warm-up + two timed steps."""
+    of --cpu-batch (default: the full batch; smaller values are scaled linearly, the cost is linear in B), one warm-up +
+    four timed steps -- about 15 s of CPU work on the GPU box's 16-thread share."""
     from bmhrl_amd import synthetic as syn
     from bmhrl_amd.model.bm_hrl_agent import agent_state_shapes
     from oracle import bmhrl_oracle as O
@@ -119,7 +120,7 @@ def cpu_baseline(args):
     one()
     print("[bench] cpu_baseline: warm-up done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    n = 2
+    n = 4
     for _ in range(n):
         one()
     dt = (time.perf_counter() - t0) / n
