@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
   // element-wise part, one variant per epilogue kind (KIND: 0 plain linear, 1 linear with mask / dropout, 2 PROB,
   // 3 DSCORE, 4 RELU_BWD); x = accumulator, returns the output value
-  auto elem = [&](auto kind, float x, float bias, float res, float aux, float rv, float rv2, int m, int n) -> float {
+  auto elem = [&](auto kind, float x, float bias, float res, float aux, float rv, float rv2, int m, int n, bool keep) -> float {
     constexpr int KIND = decltype(kind)::value;
     if constexpr (KIND == 0) {
       x = x * p.alpha + bias;
@@ -262,13 +262,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
       return x + res;
     } else if constexpr (KIND == 1) {
       x = x * p.alpha + bias;
-      if (Mg && !Mg[(long)m * p.mask_sm + n]) x = NEG_MASK;
+      if (!keep) x = NEG_MASK;
       if (p.relu) x = fmaxf(x, 0.f);
       if (p.dropout_p > 0.f) x *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n);
       return x + res;
     } else if constexpr (KIND == 2) {
       x = x * p.alpha;
-      if (Mg && !Mg[(long)m * p.mask_sm + n]) x = NEG_MASK;
+      if (!keep) x = NEG_MASK;
       return __expf(x - rv) * rv2;
     } else if constexpr (KIND == 3) {
       return aux * (x - rv) * p.alpha;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
       if (m < p.M && n < p.N) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * SC + c4);
         const float rv = RVg ? RVg[m] : 0.f;
-        const float rv2 = RV2g ? 1.f / RV2g[m] : 1.f;
+        const float rv2 = RV2g ? __builtin_amdgcn_rcpf(RV2g[m]) : 1.f;      // 1 ulp reciprocal: P is rounded to bf16 anyway
         if (p.vec_ok && n + 4 <= p.N) {
           f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = {0.f, 0.f, 0.f, 0.f}, x4 = {0.f, 0.f, 0.f, 0.f};
           if (biasp) b4 = *reinterpret_cast<const f32x4*>(biasp + n);
@@ -301,9 +301,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             const bf16x4 t = *reinterpret_cast<const bf16x4*>(AUXg + (long)m * p.ldaux + n);
             x4[0] = (float)t[0]; x4[1] = (float)t[1]; x4[2] = (float)t[2]; x4[3] = (float)t[3];
           }
+          uint32_t keep4 = 0x01010101u;        // mask bytes of the 4 columns (one 4-byte load when aligned)
+          if constexpr (decltype(kind)::value == 1 || decltype(kind)::value == 2) {
+            if (Mg) {
+              const uint8_t* mp = Mg + (long)m * p.mask_sm + n;
+              if (((uintptr_t)mp & 3) == 0) keep4 = *reinterpret_cast<const uint32_t*>(mp);
+              else keep4 = (uint32_t)mp[0] | ((uint32_t)mp[1] << 8) | ((uint32_t)mp[2] << 16) | ((uint32_t)mp[3] << 24);
+            }
+          }
           f32x4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j);
+          for (int j = 0; j < 4; ++j)
+            o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j, ((keep4 >> (8 * j)) & 0xffu) != 0);
           cs4 += o;
           if (Cg) {
             float* dst = Cg + (long)m * p.ldc + n;
@@ -325,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             const float b = biasp ? biasp[n + j] : 0.f;
             const float r = Rg ? Rg[(long)m * p.ldr + n + j] : 0.f;
             const float ax = AUXg ? (float)AUXg[(long)m * p.ldaux + n + j] : 0.f;
-            const float o = elem(kind, a4[j], b, r, ax, rv, rv2, m, n + j);
+            const bool keep = !Mg || Mg[(long)m * p.mask_sm + n + j] != 0;
+            const float o = elem(kind, a4[j], b, r, ax, rv, rv2, m, n + j, keep);
             cs4[j] += o;
             if (Cg) {
               float* dst = Cg + (long)m * p.ldc + n + j;
