@@ -168,7 +168,9 @@ class BMFusion(nn.Module):
 
 class SegmentCritic(nn.Module):
     """Frozen LSTM(4) -> AReLU -> GRU(2) -> AReLU -> Linear segment scorer, reference :186-215.
-    Runs under no_grad on torch's RNN kernels (not on the north-star kernel list).
+    On the GPU it runs on the fp32 HIP kernels of csrc/critic.hip (score_and_labels: f32-MFMA input projections, one
+    launch per time step, fused score / threshold head) so the int segment labels equal the reference's exactly; the
+    nn.LSTM / nn.GRU modules only hold the parameters (reference state-dict keys) and serve CPU tensors.
     `cfg.rl_critic_path` is loaded when given; None leaves the (frozen) default initialisation in place."""
 
     def __init__(self, cfg):
