@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("rowvec", ptr), ("rowvec2", ptr), ("rv_sb1", i64), ("rv_sb2", i64),
         ("aux", ptr), ("ldaux", i64), ("aux_sb1", i64), ("aux_sb2", i64),
         ("dropout_p", f32), ("seed", u64), ("drop_sb1", i64), ("drop_sb2", i64), ("drop_sm", i64), ("seed_dev", ptr),
-        ("colsum", ptr), ("colsum_sb2", i64),
+        ("colsum", ptr), ("colsum_sb2", i64), ("bias_sb2", i64),
     ]
 
 

@@ -31,7 +31,7 @@ struct GemmArgs {
   const float* rowvec; const float* rowvec2; long rv_sb1, rv_sb2;
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
-  float* colsum; long cs_sb2;
+  float* colsum; long cs_sb2, bias_sb2;
   int tiles_m, splits, k_per_split, vec_ok, dbg;
 };
 
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
   const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
   const bool first_split = blockIdx.y == 0;
-  const float* __restrict__ biasp = first_split ? p.bias : nullptr;
+  const float* __restrict__ biasp = (first_split && p.bias) ? p.bias + b2 * p.bias_sb2 : nullptr;
   if (!first_split) Rg = nullptr;
 
   // element-wise part, one variant per epilogue kind (KIND: 0 plain linear, 1 linear with mask / dropout, 2 PROB,
@@ -430,7 +430,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.aux = (const bf16_t*)d->aux; a.ldaux = d->ldaux; a.aux_sb1 = d->aux_sb1; a.aux_sb2 = d->aux_sb2;
   a.dropout_p = d->dropout_p; a.seed = d->seed; a.seed_dev = d->seed_dev; a.tiles_m = 0;
   a.drop_sb1 = d->drop_sb1; a.drop_sb2 = d->drop_sb2; a.drop_sm = d->drop_sm;
-  a.colsum = d->colsum; a.cs_sb2 = d->colsum_sb2;
+  a.colsum = d->colsum; a.cs_sb2 = d->colsum_sb2; a.bias_sb2 = d->bias_sb2;
   if (a.drop_sb1 == 0 && a.drop_sb2 == 0 && a.drop_sm == 0) {
     a.drop_sm = d->N; a.drop_sb2 = (long)d->M * d->N; a.drop_sb1 = a.drop_sb2 * d->batch2;
   }
@@ -440,7 +440,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.vec_ok = al(d->C, 16) && d->ldc % 4 == 0 && d->c_sb1 % 4 == 0 && d->c_sb2 % 4 == 0 && al(d->Cb, 8) && d->ldcb % 4 == 0 &&
              d->cb_sb1 % 4 == 0 && d->cb_sb2 % 4 == 0 && al(d->residual, 16) && d->ldr % 4 == 0 && d->r_sb1 % 4 == 0 &&
              d->r_sb2 % 4 == 0 && al(d->aux, 8) && d->ldaux % 4 == 0 && d->aux_sb1 % 4 == 0 && d->aux_sb2 % 4 == 0 &&
-             al(d->bias, 16);
+             al(d->bias, 16) && d->bias_sb2 % 4 == 0;
   const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
   const long small_tiles = (long)((d->M + 63) / 64) * ((d->N + 63) / 64) * batch;
   // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight

@@ -150,6 +150,7 @@ class StepScratch:
         self.need = 0
         self.pool = {}
         self.cursor = {}
+        self.memo = {}
 
     def begin_step(self, device):
         device = torch.device(device)
@@ -161,6 +162,7 @@ class StepScratch:
             self.arena[:self.off].zero_()
         self.off = self.spill = 0
         self.cursor = {}
+        self.memo = {}
         self.armed = True
 
     def end_step(self):
@@ -180,6 +182,20 @@ class StepScratch:
         t = a[self.off:self.off + n].view(*shape)
         self.off += n4
         return t
+
+    def memo_bf16(self, t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+        """bf16 (rows, pad8(cols)) copy of the fp32 tensor t; inside a step the copy is made once per distinct tensor
+        (the encoder memory is read by every fusion layer of both stacks)."""
+        key = (t.data_ptr(), t._version, rows, cols)
+        if self.armed:
+            hit = self.memo.get(key)
+            if hit is not None and hit[0]() is t:
+                return hit[1]
+        buf = self.bf16(rows, cols, t.device)
+        ops.cast_bf16(t.contiguous(), cols, buf, buf.shape[1], rows, cols)
+        if self.armed:
+            self.memo[key] = (weakref.ref(t), buf)
+        return buf
 
     def bf16(self, rows: int, cols: int, device) -> torch.Tensor:
         if cols % 8 == 0 or not self.armed:
@@ -468,6 +484,138 @@ class MHAFn(torch.autograd.Function):
             if residual:
                 dx = dx + dy
         return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None, None)
+
+
+class MemAttnFn(torch.autograd.Function):
+    """x + dropout( d2Q( attention( Q2d(LN(x)), K2d(mem), V2d(mem), mask ) ) ) for FEW queries against a LONG memory
+    (the caption -> encoder-memory attentions of BMFusionLayer: 30 caption positions against 256 video / 800 audio
+    positions; model/bm_hrl_agent.py:91-94 around model/multihead_attention.py:60-92).
+
+    Same function as MHAFn's cross-attention branch, evaluated in an order that never projects the memory:
+        scores_h = Q_h K_h^T = Q_h (mem Wk_h^T + bk_h)^T = (Q_h Wk_h) mem^T + (Q_h . bk_h) 1^T
+    the last term is constant along the keys and cancels in the softmax (exactly; the -1e9 fill is unaffected), and
+        P_h V_h = P_h (mem Wv_h^T + 1 bv_h^T) = (P_h mem) Wv_h^T + bv_h            (rows of P sum to 1).
+    So the keys / values of the memory are the memory itself, and the two d_model-wide projections move to the query
+    side: per layer 2 x 480 rows instead of 2 x 12 800 (audio) / 4 096 (video) rows -- the K|V projection GEMMs, their
+    weight- and input-gradient GEMMs and the memory casts (about a fifth of the step's FLOPs at config 2) disappear.
+    bk gets an exactly-zero gradient (the reference's is fp32 noise around zero).  All tensors of the attention proper
+    are laid out (B, L, H, .) so that sums over heads are plain GEMMs with K = L*H."""
+
+    @staticmethod
+    def forward(ctx, x, mem, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop):
+        dev = x.device
+        B, L, dq = x.shape
+        _, Sk, dm = mem.shape
+        D = wq.shape[0]
+        dk = D // H
+        rows = B * L
+        x = x.contiguous()
+        ldx, dmp, Skp = pad8(dq), pad8(dm), pad8(Sk)
+        scale = 1.0 / math.sqrt(dk)
+        xb = SCRATCH.bf16(rows, dq, dev)
+        mean = torch.empty(rows, device=dev)
+        rstd = torch.empty(rows, device=dev)
+        ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), xb, ldx, None, mean, rstd, rows, dq)
+        s_attn, s_res = SEEDS.next(), SEEDS.next()
+        w_q, w_k, w_v, w_o = SHADOWS.weight(wq), SHADOWS.weight(wk), SHADOWS.weight(wv), SHADOWS.weight(wo)
+        Qb = torch.empty(rows, D, dtype=_BF16, device=dev)
+        ops.gemm(xb, w_q, rows, D, dq, lda=ldx, ldb=w_q.shape[1], C_bf16=Qb, ldcb=D, bias=bq.detach())
+        memb = SCRATCH.memo_bf16(mem, B * Sk, dm)                   # bf16 copy of the memory, shared by every layer of a step
+        zeros = torch.zeros if dmp != dm else torch.empty           # per-head padding columns must be zero (operands)
+        # Q'_h = Q_h Wk_h : (rows, dk) x (dk, dm)
+        Qp = zeros(rows, H * dmp, dtype=_BF16, device=dev)
+        ops.gemm(Qb, w_k, rows, dm, dk, lda=D, ldb=w_k.shape[1], b_trans=True, batch=(1, H), a_strides=(0, dk),
+                 b_strides=(0, dk * w_k.shape[1]), C_bf16=Qp, ldcb=H * dmp, cb_strides=(0, dmp))
+        m8, msb, msq = _mask_u8(mask)
+        # scores (B, L, H, Sk) = scale * Q'_h mem^T, masked
+        S = torch.empty(B, L, H, Skp, device=dev)
+        ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
+                 C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb, mask_sm=msq)
+        P = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+        ops.softmax_rows(S, Skp, P, Skp, B * L * H, Sk)
+        # context in memory space (B, L, H, dm) = P_h mem
+        Cx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
+        ops.gemm(P, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=(L * H * Skp, Skp),
+                 b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        # O_h = dropout(Cx_h Wv_h^T + bv_h)
+        Ob = torch.empty(rows, D, dtype=_BF16, device=dev)
+        ops.gemm(Cx, w_v, rows, dk, dm, lda=H * dmp, ldb=w_v.shape[1], batch=(1, H), a_strides=(0, dmp),
+                 b_strides=(0, dk * w_v.shape[1]), C_bf16=Ob, ldcb=D, cb_strides=(0, dk), bias=bv.detach(), bias_sb2=dk,
+                 dropout_p=p_drop, seed=s_attn, seed_dev=SEEDS.dev, drop_strides=(0, dk, D))
+        y = torch.empty(B, L, dq, device=dev)
+        ops.gemm(Ob, w_o, rows, dq, D, lda=D, ldb=w_o.shape[1], C_f32=y, ldc=dq, bias=bo.detach(), residual=x, ldr=dq,
+                 dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+        ctx.save_for_backward(x, ln_w, mean, rstd, xb, memb, Qb, Qp, P, Cx, Ob, wq, wk, wv, wo)
+        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res = ctx.cfg
+        x, ln_w, mean, rstd, xb, memb, Qb, Qp, P, Cx, Ob, wq, wk, wv, wo = ctx.saved_tensors
+        dev = dy.device
+        rows = B * L
+        ldx, dmp, Skp = pad8(dq), pad8(dm), pad8(Sk)
+        scale = 1.0 / math.sqrt(dk)
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        w_q, w_k, w_v, w_o = SHADOWS.weight(wq), SHADOWS.weight(wk), SHADOWS.weight(wv), SHADOWS.weight(wo)
+        zeros = torch.zeros if dmp != dm else torch.empty
+        # out projection: dWo, dbo; d(attention output) back through its dropout, with the column sums = dbv
+        dyb, dbo = _cast_dy(dy, rows, dq, p_drop, s_res, need[11])
+        dOb = torch.empty(rows, D, dtype=_BF16, device=dev)
+        dbv = SCRATCH.f32(D, device=dev) if need[9] else None
+        dwo, _ = _linear_bwd(dyb, ldx, rows, dq, Ob, D, D, w_o, need_dw=need[10], need_db=False, need_dx=True,
+                             dx_bf16=dOb, lddxb=D, dx_drop=p_drop, dx_seed=s_attn, dx_colsum=dbv)
+        # O_h = Cx_h Wv_h^T + bv_h
+        dwv = None
+        if need[8]:
+            dwv = SCRATCH.f32(D, dm, device=dev)
+            ops.gemm(dOb, Cx, dk, dm, rows, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(1, H), a_strides=(0, dk),
+                     b_strides=(0, dmp), C_f32=dwv, ldc=dm, c_strides=(0, dk * dm), allow_split_k=True)
+        dCx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
+        ops.gemm(dOb, w_v, rows, dm, dk, lda=D, ldb=w_v.shape[1], b_trans=True, batch=(1, H), a_strides=(0, dk),
+                 b_strides=(0, dk * w_v.shape[1]), C_bf16=dCx, ldcb=H * dmp, cb_strides=(0, dmp))
+        # softmax backward: delta = sum_k P dP = sum_n dCx Cx ; dS = P (dP - delta) * scale with dP = dCx_h mem^T
+        delta = torch.empty(B, H, L, device=dev)
+        ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B, H, L, dmp)
+        dS = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+        pstr = (L * H * Skp, Skp)
+        ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
+                 C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
+                 rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
+        # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h : two GEMMs with K = L*H (rows (l, h) of the (B, L, H, .) tensors)
+        dmem = None
+        if need[1]:
+            dmem = torch.empty(B, Sk, dm, device=dev)
+            ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
+                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=dmem, ldc=dm, c_strides=(Sk * dm, 0))
+            ops.gemm(dS, Qp, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
+                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=dmem, ldc=dm, c_strides=(Sk * dm, 0),
+                     accumulate=True)
+        # scores = scale * Q'_h mem^T (scale is already inside dS)
+        dQp = zeros(rows, H * dmp, dtype=_BF16, device=dev)
+        ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
+                 C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        # Q'_h = Q_h Wk_h
+        dwk = None
+        if need[6]:
+            dwk = SCRATCH.f32(D, dm, device=dev)
+            ops.gemm(Qb, dQp, dk, dm, rows, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(1, H), a_strides=(0, dk),
+                     b_strides=(0, dmp), C_f32=dwk, ldc=dm, c_strides=(0, dk * dm), allow_split_k=True)
+        dbq = SCRATCH.f32(D, device=dev) if need[5] else None
+        dQb = torch.empty(rows, D, dtype=_BF16, device=dev)
+        ops.gemm(dQp, w_k, rows, dk, dm, lda=H * dmp, ldb=w_k.shape[1], batch=(1, H), a_strides=(0, dmp),
+                 b_strides=(0, dk * w_k.shape[1]), C_bf16=dQb, ldcb=D, cb_strides=(0, dk), colsum=dbq, colsum_sb2=dk)
+        dbk = SCRATCH.f32(D, device=dev) if need[7] else None       # exactly zero: a shift of all keys' scores
+        # Q projection and LayerNorm
+        dxn = torch.empty(rows, dq, device=dev)
+        dwq, _ = _linear_bwd(dQb, D, rows, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=False, need_dx=True, dx_f32=dxn)
+        dx = torch.empty(B, L, dq, device=dev)
+        dlnw = SCRATCH.f32(dq, device=dev) if need[2] else None
+        dlnb = SCRATCH.f32(dq, device=dev) if need[3] else None
+        ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy, dlnw, dlnb, rows, dq)
+        return (dx, dmem, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None)
 
 
 class AttnCoreFn(torch.autograd.Function):

@@ -138,20 +138,30 @@ class BMFusionLayer(nn.Module):
             side = cls._side
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                Ca = self.enc_att_A.fused(C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, residual=True, kv_cache=kvc)
+                Ca = self._memory_att(self.enc_att_A, C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, kvc)
                 Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
-            Cv = self.enc_att_V.fused(C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, residual=True, kv_cache=kvc)
+            Cv = self._memory_att(self.enc_att_V, C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, kvc)
             Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
             main.wait_stream(side)
             return GateFn.apply(Cv, Ca, self.a_v_constant), memory
-        Ca = self.enc_att_A.fused(C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, residual=True, kv_cache=kvc)
-        Cv = self.enc_att_V.fused(C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, residual=True, kv_cache=kvc)
+        Ca = self._memory_att(self.enc_att_A, C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, kvc)
+        Cv = self._memory_att(self.enc_att_V, C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, kvc)
         Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
         Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
         return GateFn.apply(Cv, Ca, self.a_v_constant), memory
 
     branch_side_stream = True
     _side = None
+    absorb_memory_projections = True
+
+    def _memory_att(self, att, C, mem, mask, norm, kv_cache):
+        """30 caption positions against a 256- / 800-long memory: the K/V projections are folded into the query side
+        (functional.MemAttnFn) instead of projecting the whole memory in every layer of both stacks.  Decoding keeps the
+        projected form: there the projection is computed once per clip and reused for every token (kv_cache); so does
+        every other no-grad call, which keeps memoised and re-run decoding bit-identical."""
+        if kv_cache is None and self.absorb_memory_projections and C.is_cuda and torch.is_grad_enabled():
+            return att.fused_memory(C, mem, mask, norm)
+        return att.fused(C, mem, mask, norm, residual=True, kv_cache=kv_cache)
 
 
 class BMFusion(nn.Module):

@@ -3,7 +3,7 @@
 import torch
 import torch.nn as nn
 
-from ..functional import AttnCoreFn, LinearFn, MHAFn
+from ..functional import AttnCoreFn, LinearFn, MemAttnFn, MHAFn
 
 
 class MultiheadedAttention(nn.Module):
@@ -36,6 +36,12 @@ class MultiheadedAttention(nn.Module):
         ln_w = norm.weight if norm is not None else None
         ln_b = norm.bias if norm is not None else None
         return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual, kv_cache)
+
+    def fused_memory(self, x, mem, mask, norm):
+        """x + drop(MHA(LN(x), mem, mem)) for few queries against a long memory: same function as fused(x, mem, ...,
+        residual=True), evaluated without ever projecting the memory (functional.MemAttnFn)."""
+        p = self.dout_p if self.training else 0.0
+        return MemAttnFn.apply(x, mem, norm.weight, norm.bias, *self._params(), mask, self.H, p)
 
     def forward(self, Q, K, V, mask, causal=False):
         """Reference signature: Q (B,Sq,Dq), K (B,Sk,Dk), V (B,Sk,Dv), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).

@@ -44,7 +44,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
          aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False,
-         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0) -> None:
+         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0, bias_sb2=0) -> None:
     """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
     _need_cuda(A, B, C_f32, C_bf16)
     d = _lib.GemmDesc()
@@ -64,6 +64,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.dropout_p = dropout_p; d.seed = seed; d.seed_dev = _p(seed_dev)
     d.drop_sb1, d.drop_sb2, d.drop_sm = drop_strides
     d.colsum = None if colsum is None else colsum.data_ptr() + 4 * colsum_off; d.colsum_sb2 = colsum_sb2
+    d.bias_sb2 = bias_sb2
     _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
 
 

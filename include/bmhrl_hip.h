@@ -62,6 +62,7 @@ typedef struct bmhrl_gemm_desc {
   const uint64_t* seed_dev;                       /* optional device word added to seed (changes under graph replay) */
   float* colsum; int64_t colsum_sb2;              /* optional: colsum[b2*colsum_sb2 + n] += sum_m v (fp32 atomics; the bias
                                                      gradient of the layer whose dY this GEMM writes); not with split-K */
+  int64_t bias_sb2;                               /* bias of batch entry (b1, b2) starts at bias + b2*bias_sb2 (per-head bias slices) */
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
