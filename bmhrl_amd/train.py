@@ -54,7 +54,9 @@ class FlatAdam:
             p.grad = None
 
     def gather_grads(self):
-        """copy the autograd gradients into the flat bucket (one multi-tensor copy); missing ones stay zero"""
+        """copy the autograd gradients into the flat bucket; missing ones stay zero.  On the GPU this is ONE launch of the
+        segmented copy kernel (bmhrl_cast_segments, fp32 mode): inside a trainer step the gradients live at fixed
+        addresses (slices of the step scratch arena), so the segment table is built once and reused."""
         dst, src, missing = [], [], []
         for p, gv in zip(self.params, self.grad_views):
             if p.grad is None:
@@ -64,8 +66,24 @@ class FlatAdam:
                 src.append(p.grad)
         if missing:
             torch._foreach_zero_(missing)
-        if dst:
+        if not dst:
+            return
+        if not self.flat.is_cuda or any((not g.is_contiguous()) or g.dtype != torch.float32 for g in src):
             torch._foreach_copy_(dst, src)
+            return
+        sig = tuple((g.data_ptr(), d.data_ptr(), g.numel()) for g, d in zip(src, dst))
+        if getattr(self, "_gather_sig", None) != sig:
+            if torch.cuda.is_current_stream_capturing():      # (cannot upload a table now; capture() warms this up first)
+                torch._foreach_copy_(dst, src)
+                return
+            rows, blk = [], 0
+            for sp, dp, n in sig:
+                rows.append([sp, dp, 1, n, 0, blk])
+                blk += (n + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
+            self._gather_plan = (torch.tensor(rows, dtype=torch.int64).to(self.flat.device), len(rows), blk)
+            self._gather_sig = sig
+        table, n_seg, n_blk = self._gather_plan
+        ops.cast_segments(table, n_seg, n_blk)
 
     def all_reduce(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
