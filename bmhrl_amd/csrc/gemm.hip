@@ -32,7 +32,7 @@ struct GemmArgs {
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
   float* colsum; long cs_sb2, bias_sb2;
-  int tiles_m, splits, k_per_split, vec_ok, dbg;
+  int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16;
 };
 
 constexpr int BK = 64;
@@ -223,6 +223,52 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   // LDS so that every thread then owns 4 consecutive columns of a row: residual / aux / mask loads and the C stores
   // are 8- or 16-byte, fully coalesced accesses instead of 2- or 4-byte ones at a 32-lane stride.
   if (p.dbg == 3) { if (acc[0][0][0] == 123.f) p.C[0] = 1.f; return; }
+  // Fast path for the most common output: bf16 only, plain linear epilogue (bias / ReLU / dropout), aligned.  The values
+  // are finished in registers (a lane owns ONE output column, so the bias is a scalar per MFMA tile), staged as bf16
+  // (half the LDS bytes of the generic fp32 staging) and written with 16-byte stores: a wave covers whole 256-byte row
+  // segments.  The projections with K = 128 (audio stream) are bound by exactly this output write.
+  if (p.fast_bf16 && p.splits == 1) {
+    constexpr int SCB = BN + 8;
+    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
+    const float* __restrict__ bp = p.bias ? p.bias + b2 * p.bias_sb2 : nullptr;
+    const uint64_t seedf = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
+    const uint64_t dbase = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
+    auto stage_bf16 = [&](const f32x16& av, const int mi, const int ni) {
+      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
+      const float bias = (bp && n < p.N) ? bp[n] : 0.f;
+      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        float v = av[r] * p.alpha + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seedf, dbase + (uint64_t)(m0 + row) * p.drop_sm + n);
+        sCb[row * SCB + col] = (bf16_t)v;
+      }
+    };
+    stage_bf16(acc[0][0], 0, 0);
+    if constexpr (TN > 1) stage_bf16(acc[0][1], 0, 1);
+    if constexpr (TM > 1) {
+      stage_bf16(acc[1][0], 1, 0);
+      if constexpr (TN > 1) stage_bf16(acc[1][1], 1, 1);
+    }
+    __syncthreads();
+    constexpr int G8 = BM * BN / 8 / 256;          // 16-byte groups per thread
+#pragma unroll
+    for (int i = 0; i < G8; ++i) {
+      const int g = tid + i * 256;
+      const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
+      const int m = m0 + row, n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
+        bf16_t* dst = Cbf + (long)m * p.ldcb + n;
+        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+        else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
+      }
+    }
+    return;
+  }
   constexpr int SC = BN + 4;
   static_assert(BM * SC * 2 <= 2 * (A_ELEMS + B_ELEMS), "C tile must fit in the staging buffers");
   float* sC = reinterpret_cast<float*>(smem);
@@ -441,6 +487,8 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
              d->cb_sb1 % 4 == 0 && d->cb_sb2 % 4 == 0 && al(d->residual, 16) && d->ldr % 4 == 0 && d->r_sb1 % 4 == 0 &&
              d->r_sb2 % 4 == 0 && al(d->aux, 8) && d->ldaux % 4 == 0 && d->aux_sb1 % 4 == 0 && d->aux_sb2 % 4 == 0 &&
              al(d->bias, 16) && d->bias_sb2 % 4 == 0;
+  a.fast_bf16 = d->Cb && !d->C && d->epilogue == BMHRL_EPI_LINEAR && !d->mask && !d->residual && !d->aux && !d->colsum &&
+                !d->accumulate && al(d->Cb, 16) && d->ldcb % 8 == 0 && d->cb_sb1 % 8 == 0 && d->cb_sb2 % 8 == 0;
   const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
   const long small_tiles = (long)((d->M + 63) / 64) * ((d->N + 63) / 64) * batch;
   // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight
