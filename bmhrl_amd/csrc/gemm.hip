@@ -499,7 +499,10 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
   static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
   bool big = force_tile ? force_tile == 2 : big_tiles >= big_min;
-  if (can_split && !force_tile && d->M >= 128 && d->N >= 128 && big_tiles <= 96 && d->K >= 1024) {
+  // (128x128 tiles + K split for small outputs: re-measured slower than 64x64 tiles + K split since the deep-prefetch /
+  //  epilogue changes -- V dW 30 vs 23 us, A-out dW 25 vs 18 us; kept behind BMHRL_GEMM_BIGSPLIT=1 as a tuning aid)
+  static const int big_split = getenv("BMHRL_GEMM_BIGSPLIT") ? atoi(getenv("BMHRL_GEMM_BIGSPLIT")) : 0;
+  if (big_split && can_split && !force_tile && d->M >= 128 && d->N >= 128 && big_tiles <= 96 && d->K >= 1024) {
     // weight gradients with a small output and a long reduction: 128x128 tiles (about 3x the rate of 64x64 ones),
     // the chip is filled through the K split
     const int ktiles = (d->K + BK - 1) / BK;
