@@ -32,7 +32,7 @@ struct GemmArgs {
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
   float* colsum; long cs_sb2, bias_sb2;
-  int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16;
+  int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16, fast_pd;
 };
 
 constexpr int BK = 64;
@@ -269,6 +269,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
     return;
   }
+  // Same idea for the two softmax epilogues of the attention backward (P recomputation, dS): the row vectors (row max /
+  // 1 / row sum, or delta) are staged in LDS once per tile (the generic path re-loads and re-divides them per 4-column
+  // group), the P tile that dS needs is brought in with 16-byte loads and updated in place, the result leaves as
+  // 16-byte stores.  These GEMMs have K = d_k = 256, i.e. four k-steps: they are all epilogue.
+  if (p.fast_pd && p.splits == 1) {
+    constexpr int SCB = BN + 8;
+    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
+    float* sRV = reinterpret_cast<float*>(smem + BM * SCB);
+    float* sRV2 = sRV + BM;
+    static_assert((BM * SCB) * 2 + 2 * BM * 4 <= 2 * (A_ELEMS + B_ELEMS) * 2, "softmax epilogue staging must fit");
+    bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
+    const bool prob = p.epilogue == BMHRL_EPI_PROB;
+    const float* __restrict__ rv = p.rowvec + b1 * p.rv_sb1 + b2 * p.rv_sb2;
+    const float* __restrict__ rv2 = prob ? p.rowvec2 + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
+    if (tid < BM) {
+      const int m = min(m0 + tid, p.M - 1);
+      sRV[tid] = rv[m];
+      sRV2[tid] = prob ? __builtin_amdgcn_rcpf(rv2[m]) : 0.f;
+    }
+    constexpr int G8 = BM * BN / 8 / 256;
+    if (!prob) {   // P tile -> LDS
+      const bf16_t* __restrict__ Pg = p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2;
+#pragma unroll
+      for (int i = 0; i < G8; ++i) {
+        const int g = tid + i * 256;
+        const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
+        const int m = m0 + row, n = n0 + c8;
+        bf16x8 v = zero_bf16x8();
+        if (m < p.M && n < p.N) {
+          const bf16_t* src = Pg + (long)m * p.ldaux + n;
+          if (n + 8 <= p.N) v = *reinterpret_cast<const bf16x8*>(src);
+          else for (int j = 0; j < 8 && n + j < p.N; ++j) v[j] = src[j];
+        }
+        *reinterpret_cast<bf16x8*>(sCb + row * SCB + c8) = v;
+      }
+    }
+    __syncthreads();
+    const uint8_t* __restrict__ Mk = (prob && p.mask) ? p.mask + b1 * p.mask_sb1 : nullptr;     // key mask (mask_sm == 0)
+    auto finish = [&](const f32x16& av, const int mi, const int ni) {
+      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
+      const bool keep = !Mk || n >= p.N || Mk[n] != 0;
+      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        bf16_t* q = sCb + row * SCB + col;
+        float v;
+        if (prob) {
+          const float x = keep ? av[r] * p.alpha : NEG_MASK;
+          v = __expf(x - sRV[row]) * sRV2[row];
+        } else {
+          v = (float)*q * (av[r] - sRV[row]) * p.alpha;
+        }
+        *q = (bf16_t)v;
+      }
+    };
+    finish(acc[0][0], 0, 0);
+    if constexpr (TN > 1) finish(acc[0][1], 0, 1);
+    if constexpr (TM > 1) {
+      finish(acc[1][0], 1, 0);
+      if constexpr (TN > 1) finish(acc[1][1], 1, 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < G8; ++i) {
+      const int g = tid + i * 256;
+      const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
+      const int m = m0 + row, n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
+        bf16_t* dst = Cbf + (long)m * p.ldcb + n;
+        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+        else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
+      }
+    }
+    return;
+  }
   constexpr int SC = BN + 4;
   static_assert(BM * SC * 2 <= 2 * (A_ELEMS + B_ELEMS), "C tile must fit in the staging buffers");
   float* sC = reinterpret_cast<float*>(smem);
@@ -489,6 +566,11 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
              al(d->bias, 16) && d->bias_sb2 % 4 == 0;
   a.fast_bf16 = d->Cb && !d->C && d->epilogue == BMHRL_EPI_LINEAR && !d->mask && !d->residual && !d->aux && !d->colsum &&
                 !d->accumulate && al(d->Cb, 16) && d->ldcb % 8 == 0 && d->cb_sb1 % 8 == 0 && d->cb_sb2 % 8 == 0;
+  const bool out_ok = d->Cb && !d->C && !d->residual && !d->colsum && !d->accumulate && !d->bias && al(d->Cb, 16) &&
+                      d->ldcb % 8 == 0 && d->cb_sb1 % 8 == 0 && d->cb_sb2 % 8 == 0 && d->rowvec;
+  a.fast_pd = (d->epilogue == BMHRL_EPI_PROB && out_ok && d->rowvec2 && (!d->mask || d->mask_sm == 0) && !d->aux) ||
+              (d->epilogue == BMHRL_EPI_DSCORE && out_ok && d->aux && al(d->aux, 16) && d->ldaux % 8 == 0 &&
+               d->aux_sb1 % 8 == 0 && d->aux_sb2 % 8 == 0);
   const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
   const long small_tiles = (long)((d->M + 63) / 64) * ((d->N + 63) / 64) * batch;
   // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight
