@@ -42,17 +42,15 @@
 
 namespace {
 
-constexpr int DK = 256;
+// The head dimension DK is a template parameter: 256 = d_model / H of the reference; 128 = the absorbed-projection form
+// of the attentions whose keys / values are the 128-wide audio stream (scores_h = (Q_h Wk_h) A^T, context_h = P_h A:
+// one key/value tile shared by all heads, half the FLOPs, and half the registers -> two workgroups per CU).
 constexpr int QW = 2, KW = 2, NT = 64 * QW * KW;
 constexpr int BN = 32 * KW;                 // keys per tile
-constexpr int VST = BN * DK;                // elements of one K or V stage (32 KiB)
-constexpr int LDS_KV = 4 * VST * 2;         // bytes: K stage 0, K stage 1, V stage 0, V stage 1
 // per-key softmax coefficients of one batch row: score2 = fma(q.k, coef[key], pen[key]) in the log2 domain
 //   valid key  : coef = scale*log2(e), pen = 0        masked key : coef = 0, pen = -1e9*log2(e)
 //   key >= Sk  : coef = 0, pen = -inf  (tile padding)
-constexpr int MAXK = 2048 + 64;
-constexpr int MERGE_FLOATS = (KW - 1) * QW * 130 * 64;
-static_assert(MERGE_FLOATS * 4 <= LDS_KV, "the merge area reuses the K/V stages");
+template <int DK> constexpr int max_keys() { return DK == 128 ? 1024 + 64 : 2048 + 64; }   // (128: 2 workgroups per CU must fit)
 
 struct AttnArgs {
   const bf16_t* Q; long ldq;
@@ -62,6 +60,7 @@ struct AttnArgs {
   float* row_max; float* row_sum;
   const uint8_t* mask; long mask_sb, mask_sq;
   int B, H, Sq, Sk;
+  long k_hs, v_hs;          // element offset of head h inside a K / V row: h * k_hs (0: one tile for all heads)
   float scale, dropout_p; uint64_t seed; const uint64_t* seed_dev;
   int q_tiles, dbg;
 };
@@ -91,8 +90,14 @@ __device__ __forceinline__ float pair_max(float v) {   // max over lanes l and l
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <bool QMASK>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
+template <int DK, bool QMASK>
+__global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int VST = BN * DK;                // elements of one K or V stage (32 / 16 KiB)
+  constexpr int LDS_KV = 4 * VST * 2;         // bytes: K stage 0, K stage 1, V stage 0, V stage 1
+  constexpr int MAXK = max_keys<DK>();
+  constexpr int OREGS = DK / 2;               // O^T accumulator registers per lane
+  constexpr int MERGE_FLOATS = (KW - 1) * QW * (OREGS + 2) * 64;
+  static_assert(MERGE_FLOATS * 4 <= LDS_KV, "the merge area reuses the K/V stages");
   __shared__ __attribute__((aligned(16))) char smem_raw[LDS_KV + 2 * MAXK * 4];
   float* s_coef = reinterpret_cast<float*>(smem_raw + LDS_KV);
   float* s_pen = s_coef + MAXK;
@@ -121,8 +126,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
   const int q_row = qt * (32 * QW) + qi * 32 + r32;       // this lane's query row
   const bool q_ok = q_row < p.Sq;
 
-  const bf16_t* __restrict__ Kg = p.K + (long)b * p.Sk * p.ldk + hd * DK;
-  const bf16_t* __restrict__ Vg = p.V + (long)b * p.Sk * p.ldv + hd * DK;
+  const bf16_t* __restrict__ Kg = p.K + (long)b * p.Sk * p.ldk + hd * p.k_hs;
+  const bf16_t* __restrict__ Vg = p.V + (long)b * p.Sk * p.ldv + hd * p.v_hs;
 
   constexpr bool key_mask = !QMASK;    // same mask for every query row (or none) -> LDS coefficients
   const int nt = (p.Sk + BN - 1) / BN;
@@ -152,15 +157,19 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
   // XOR-swizzled in LDS -- K: 16-byte chunk ^= row & 15 (the 16 rows of a ds_read_b128 group hit 16 different slots),
   // V: chunk ^= (row & 3) << 2 (the 4 rows of a transposed-read block hit 4 different bank quarters) -- and the
   // swizzle is applied on the SOURCE address.
-  constexpr int GL = BN / 2 / (QW * KW);               // = 8 instructions per wave per operand per tile
-  const int hi = lane >> 5, pch = lane & 31;
+  constexpr int CPR = DK / 8;                          // 16-byte chunks per row (32 / 16)
+  constexpr int RPI = 64 / CPR;                        // rows per instruction (2 / 4): one wave instruction moves 1 KiB
+  constexpr int GL = BN / (QW * KW) / RPI;             // instructions per wave per operand per tile (8 / 4)
+  const int hi = lane / CPR, pch = lane % CPR;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const int wrow = wave_s * (BN / (QW * KW));
-  int koff[GL], voff[2];                               // lane part of the source offsets (elements)
+  int koff[GL], voff[GL];                              // lane part of the source offsets (elements)
 #pragma unroll
-  for (int i = 0; i < GL; ++i) koff[i] = hi * (int)p.ldk + ((pch ^ (2 * i + hi)) << 3);
-#pragma unroll
-  for (int bb = 0; bb < 2; ++bb) voff[bb] = hi * (int)p.ldv + ((pch ^ ((2 * bb + hi) << 2)) << 3);
+  for (int i = 0; i < GL; ++i) {
+    const int r = RPI * i + hi;                        // row inside the wave's 16-row group
+    koff[i] = hi * (int)p.ldk + ((pch ^ (r & 15)) << 3);
+    voff[i] = hi * (int)p.ldv + ((pch ^ ((r & 3) << 2)) << 3);
+  }
   auto glds16 = [](const bf16_t* src, bf16_t* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -171,13 +180,13 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
     if (k0 + BN <= p.Sk) {
       const bf16_t* Kt = Kg + (long)(k0 + wrow) * p.ldk;          // uniform
 #pragma unroll
-      for (int i = 0; i < GL; ++i) glds16(Kt + (long)(2 * i) * p.ldk + koff[i], sK + 2 * i * DK);
+      for (int i = 0; i < GL; ++i) glds16(Kt + (long)(RPI * i) * p.ldk + koff[i], sK + RPI * i * DK);
     } else {   // ragged last tile: clamp the key row (its score gets pen = -inf, so P is exactly 0 there)
 #pragma unroll
       for (int i = 0; i < GL; ++i) {
-        const int r = 2 * i + hi;
+        const int r = RPI * i + hi;
         const long gr = min(k0 + wrow + r, p.Sk - 1);
-        glds16(Kg + gr * p.ldk + ((pch ^ r) << 3), sK + 2 * i * DK);
+        glds16(Kg + gr * p.ldk + ((pch ^ (r & 15)) << 3), sK + RPI * i * DK);
       }
     }
   };
@@ -187,13 +196,13 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
     if (k0 + BN <= p.Sk) {
       const bf16_t* Vt = Vg + (long)(k0 + wrow) * p.ldv;          // uniform
 #pragma unroll
-      for (int i = 0; i < GL; ++i) glds16(Vt + (long)(2 * i) * p.ldv + voff[i & 1], sV + 2 * i * DK);
+      for (int i = 0; i < GL; ++i) glds16(Vt + (long)(RPI * i) * p.ldv + voff[i], sV + RPI * i * DK);
     } else {   // ragged: the probability is exactly 0 there, but the data must be finite
 #pragma unroll
       for (int i = 0; i < GL; ++i) {
-        const int r = 2 * i + hi;
+        const int r = RPI * i + hi;
         const long gr = min(k0 + wrow + r, p.Sk - 1);
-        glds16(Vg + gr * p.ldv + ((pch ^ ((r & 3) << 2)) << 3), sV + 2 * i * DK);
+        glds16(Vg + gr * p.ldv + ((pch ^ ((r & 3) << 2)) << 3), sV + RPI * i * DK);
       }
     }
   };
@@ -264,10 +273,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
         BMHRL_RESCALE_TILE(1, a16, a17, a18, a19, a20, a21, a22, a23, a24, a25, a26, a27, a28, a29, a30, a31, "a[16:31]")
         BMHRL_RESCALE_TILE(2, a32, a33, a34, a35, a36, a37, a38, a39, a40, a41, a42, a43, a44, a45, a46, a47, "a[32:47]")
         BMHRL_RESCALE_TILE(3, a48, a49, a50, a51, a52, a53, a54, a55, a56, a57, a58, a59, a60, a61, a62, a63, "a[48:63]")
+        if constexpr (DK == 256) {
         BMHRL_RESCALE_TILE(4, a64, a65, a66, a67, a68, a69, a70, a71, a72, a73, a74, a75, a76, a77, a78, a79, "a[64:79]")
         BMHRL_RESCALE_TILE(5, a80, a81, a82, a83, a84, a85, a86, a87, a88, a89, a90, a91, a92, a93, a94, a95, "a[80:95]")
         BMHRL_RESCALE_TILE(6, a96, a97, a98, a99, a100, a101, a102, a103, a104, a105, a106, a107, a108, a109, a110, a111, "a[96:111]")
         BMHRL_RESCALE_TILE(7, a112, a113, a114, a115, a116, a117, a118, a119, a120, a121, a122, a123, a124, a125, a126, a127, "a[112:127]")
+        }
 #undef BMHRL_RS1
 #undef BMHRL_RESCALE_TILE
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -300,28 +311,48 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
   auto qk_issue = [&](const unsigned koffs) {
 #pragma unroll
     for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(kf[st]) : "v"(k_addr[st] + koffs));
+    if constexpr (DK == 256) {
 #pragma unroll
-    for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(kf[8 + st]) : "v"(k_addr[st] + koffs));
+      for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(kf[8 + st]) : "v"(k_addr[st] + koffs));
+    }
   };
+  // `step(e)` is called 16 times over the chain (one exponential of the previous tile per call)
   auto qk_chain = [&](auto&& mid, auto&& step) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
-    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+    if constexpr (DK == 256) {
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
-      step(st);
-    }
-    mid();
-    // in-order returns: at most 15 younger reads outstanding means the 16 K fragments are all there
-    asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[8]), "+v"(kf[9]), "+v"(kf[10]), "+v"(kf[11]), "+v"(kf[12]), "+v"(kf[13]), "+v"(kf[14]), "+v"(kf[15]));
+      for (int st = 0; st < 8; ++st) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
+        step(st);
+      }
+      mid();
+      // in-order returns: at most 15 younger reads outstanding means the 16 K fragments are all there
+      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[8]), "+v"(kf[9]), "+v"(kf[10]), "+v"(kf[11]), "+v"(kf[12]), "+v"(kf[13]), "+v"(kf[14]), "+v"(kf[15]));
 #pragma unroll
-    for (int st = 8; st < 16; ++st) {
-      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
-      step(st);
+      for (int st = 8; st < 16; ++st) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
+        step(st);
+      }
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
+        step(2 * st);
+        step(2 * st + 1);
+      }
+      mid();                                   // 16 V^T reads: younger than every K fragment
+      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
+#pragma unroll
+      for (int st = 4; st < 8; ++st) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
+        step(2 * st);
+        step(2 * st + 1);
+      }
     }
   };
-
 
   __syncthreads();   // coefficients written; also drains the first K/V stages (direct-to-LDS loads count on vmcnt)
   qk_issue(0u);
@@ -400,11 +431,13 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
     }
     wait_vt();
     pv(0);
-    read_vt(soff, H1{});
+    if constexpr (DK == 256) read_vt(soff, H1{});
     c_addr += BN * 4;
     float m_tile = scale_scores_fast(s_acc, sc);   // independent of the MFMAs around it: the VALU work hides under them
-    wait_vt();
-    pv(4);
+    if constexpr (DK == 256) {
+      wait_vt();
+      pv(4);
+    }
     if ((slow_bits >> (t + 1)) & 1) {              // wave-uniform, rare: redo the scores with the per-key coefficients
       f32x4 cf[4], pn[4];
       read_coef(c_addr, cf, pn);
@@ -434,9 +467,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
     pack_p();
     wait_vt();
     pv(0);
-    read_vt(soff, H1{});
-    wait_vt();
-    pv(4);
+    if constexpr (DK == 256) {
+      read_vt(soff, H1{});
+      wait_vt();
+      pv(4);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();             // every wave is done with the V stages: the merge below reuses them
     asm volatile("" ::: "memory");
@@ -445,22 +480,22 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
   // ---- merge the KW partial states of each query block (ki > 0 publish through LDS, ki == 0 combines)
   if (KW > 1) {
     float* mg = reinterpret_cast<float*>(smem_raw);
-    // layout: [(ki-1)*QW + qi][130 rows][64 lanes] ; rows 0..127 = o regs, 128 = m, 129 = l
+    // layout: [(ki-1)*QW + qi][130 rows][64 lanes] ; rows 0..OREGS-1 = o regs, then m, then l
     if (ki > 0) {
-      float* dst = mg + ((ki - 1) * QW + qi) * 130 * 64 + lane;
+      float* dst = mg + ((ki - 1) * QW + qi) * (OREGS + 2) * 64 + lane;
 #pragma unroll
       for (int d = 0; d < DK / 32; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = o[d][r];
-      dst[128 * 64] = m_run;
-      dst[129 * 64] = l_run;
+      dst[OREGS * 64] = m_run;
+      dst[(OREGS + 1) * 64] = l_run;
     }
     __syncthreads();
     if (ki == 0) {
 #pragma unroll
       for (int k2 = 1; k2 < KW; ++k2) {
-        const float* src = mg + ((k2 - 1) * QW + qi) * 130 * 64 + lane;
-        const float m2 = src[128 * 64], l2 = src[129 * 64];
+        const float* src = mg + ((k2 - 1) * QW + qi) * (OREGS + 2) * 64 + lane;
+        const float m2 = src[OREGS * 64], l2 = src[(OREGS + 1) * 64];
         const float m = fmaxf(m_run, m2);
         const float ms = (m == -INFINITY) ? 0.f : m;
         const float a1 = __builtin_amdgcn_exp2f(m_run - ms), a2 = __builtin_amdgcn_exp2f(m2 - ms);
@@ -554,6 +589,7 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
                                    int64_t mask_sb, int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk,
                                    int32_t dk, float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                    bmhrl_stream_t stream) {
+  constexpr int DK = 256;
   BMHRL_CHECK_ARG(Q && K && V && O && row_max && row_sum);
   BMHRL_CHECK_ARG(dk == DK);  // d_model 1024 / H 4 of the reference; other head sizes use the materialised path
   BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 2048);
@@ -566,11 +602,35 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
   a.O = (bf16_t*)O; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
   a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev;
+  a.k_hs = DK; a.v_hs = DK;
   a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
   a.dbg = getenv("BMHRL_ATTN_DBG") ? atoi(getenv("BMHRL_ATTN_DBG")) : 0;
   dim3 grid((unsigned)(B * H * a.q_tiles)), block(NT);
-  if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
+  if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<DK, true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<DK, false>), grid, block, 0, (hipStream_t)stream, a);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo,
+                                             float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
+                                             int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale,
+                                             bmhrl_stream_t stream) {
+  constexpr int DK = 128;
+  BMHRL_CHECK_ARG(Qp && X && ctx && row_max && row_sum);
+  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 1024);
+  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldx % 8 == 0 && ldo % 4 == 0);
+  BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldx >= DK && ldo >= (int64_t)H * DK);
+  BMHRL_CHECK_ARG((((uintptr_t)Qp | (uintptr_t)X) & 15) == 0 && ((uintptr_t)ctx & 7) == 0);
+  AttnArgs a;
+  a.Q = (const bf16_t*)Qp; a.ldq = ldq; a.K = (const bf16_t*)X; a.ldk = ldx; a.V = (const bf16_t*)X; a.ldv = ldx;
+  a.O = (bf16_t*)ctx; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
+  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = 0;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = 0.f; a.seed = 0; a.seed_dev = nullptr;
+  a.k_hs = 0; a.v_hs = 0;                       // one 128-wide key / value row for every head
+  a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
+  a.dbg = 0;
+  dim3 grid((unsigned)(B * H * a.q_tiles)), block(NT);
+  hipLaunchKernelGGL((attn_fwd_kernel<DK, false>), grid, block, 0, (hipStream_t)stream, a);
   return hip_status(hipGetLastError());
 }
 

@@ -503,9 +503,12 @@ class MemAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mem, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop):
+        # mem is None: self attention -- the memory is LN(x) itself (keys / values of the reference's self attention
+        # are projections of the normalised input), and its gradient joins the one of the query path
         dev = x.device
         B, L, dq = x.shape
-        _, Sk, dm = mem.shape
+        self_att = mem is None
+        Sk, dm = (L, dq) if self_att else mem.shape[1:]
         D = wq.shape[0]
         dk = D // H
         rows = B * L
@@ -520,23 +523,35 @@ class MemAttnFn(torch.autograd.Function):
         w_q, w_k, w_v, w_o = SHADOWS.weight(wq), SHADOWS.weight(wk), SHADOWS.weight(wv), SHADOWS.weight(wo)
         Qb = torch.empty(rows, D, dtype=_BF16, device=dev)
         ops.gemm(xb, w_q, rows, D, dq, lda=ldx, ldb=w_q.shape[1], C_bf16=Qb, ldcb=D, bias=bq.detach())
-        memb = SCRATCH.memo_bf16(mem, B * Sk, dm)                   # bf16 copy of the memory, shared by every layer of a step
+        # bf16 memory rows: LN(x) for self attention, else a copy of the memory shared by every layer of a step
+        memb = xb if self_att else SCRATCH.memo_bf16(mem, B * Sk, dm)
         zeros = torch.zeros if dmp != dm else torch.empty           # per-head padding columns must be zero (operands)
         # Q'_h = Q_h Wk_h : (rows, dk) x (dk, dm)
         Qp = zeros(rows, H * dmp, dtype=_BF16, device=dev)
         ops.gemm(Qb, w_k, rows, dm, dk, lda=D, ldb=w_k.shape[1], b_trans=True, batch=(1, H), a_strides=(0, dk),
                  b_strides=(0, dk * w_k.shape[1]), C_bf16=Qp, ldcb=H * dmp, cb_strides=(0, dmp))
         m8, msb, msq = _mask_u8(mask)
-        # scores (B, L, H, Sk) = scale * Q'_h mem^T, masked
-        S = torch.empty(B, L, H, Skp, device=dev)
-        ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
-                 C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb, mask_sm=msq)
-        P = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
-        ops.softmax_rows(S, Skp, P, Skp, B * L * H, Sk)
-        # context in memory space (B, L, H, dm) = P_h mem
         Cx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
-        ops.gemm(P, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=(L * H * Skp, Skp),
-                 b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        flash = dm == 128 and L >= 128 and Sk <= 1024 and msq == 0
+        if flash:
+            # many queries against the 128-wide (audio) rows: fused kernel, one key / value tile for all heads; the
+            # probabilities are recomputed in backward from the softmax statistics
+            rmax = torch.empty(B, H, L, device=dev)
+            rsum = torch.empty(B, H, L, device=dev)
+            ops.attention_shared128_fwd(Qp, memb, Cx, rmax, rsum, m8, msb, B, H, L, Sk, scale, H * dmp, dmp, H * dmp)
+            stats = (rmax, rsum)
+        else:
+            # scores (B, L, H, Sk) = scale * Q'_h mem^T, masked
+            S = torch.empty(B, L, H, Skp, device=dev)
+            ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
+                     b_strides=(Sk * dmp, 0), C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8,
+                     mask_sb1=msb, mask_sm=msq)
+            P = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+            ops.softmax_rows(S, Skp, P, Skp, B * L * H, Sk)
+            # context in memory space (B, L, H, dm) = P_h mem
+            ops.gemm(P, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=(L * H * Skp, Skp),
+                     b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+            stats = (P,)
         # O_h = dropout(Cx_h Wv_h^T + bv_h)
         Ob = torch.empty(rows, D, dtype=_BF16, device=dev)
         ops.gemm(Cx, w_v, rows, dk, dm, lda=H * dmp, ldb=w_v.shape[1], batch=(1, H), a_strides=(0, dmp),
@@ -545,14 +560,15 @@ class MemAttnFn(torch.autograd.Function):
         y = torch.empty(B, L, dq, device=dev)
         ops.gemm(Ob, w_o, rows, dq, D, lda=D, ldb=w_o.shape[1], C_f32=y, ldc=dq, bias=bo.detach(), residual=x, ldr=dq,
                  dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
-        ctx.save_for_backward(x, ln_w, mean, rstd, xb, memb, Qb, Qp, P, Cx, Ob, wq, wk, wv, wo)
-        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res)
+        ctx.save_for_backward(x, ln_w, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, wq, wk, wv, wo, m8, *stats)
+        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res = ctx.cfg
-        x, ln_w, mean, rstd, xb, memb, Qb, Qp, P, Cx, Ob, wq, wk, wv, wo = ctx.saved_tensors
+        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb = ctx.cfg
+        x, ln_w, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, wq, wk, wv, wo, m8 = ctx.saved_tensors[:15]
+        stats = ctx.saved_tensors[15:]
         dev = dy.device
         rows = B * L
         ldx, dmp, Skp = pad8(dq), pad8(dm), pad8(Sk)
@@ -581,18 +597,28 @@ class MemAttnFn(torch.autograd.Function):
         ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B, H, L, dmp)
         dS = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
         pstr = (L * H * Skp, Skp)
+        if flash:      # P (B, L, H, Sk) recomputed from the statistics of the fused forward
+            P = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+            ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
+                     b_strides=(Sk * dmp, 0), C_bf16=P, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
+                     mask=m8, mask_sb1=msb, mask_sm=0, rowvec=stats[0], rowvec2=stats[1], rv_strides=(H * L, L))
+        else:
+            P = stats[0]
         ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
                  C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
                  rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
         # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h : two GEMMs with K = L*H (rows (l, h) of the (B, L, H, .) tensors)
-        dmem = None
-        if need[1]:
-            dmem = torch.empty(B, Sk, dm, device=dev)
+        def grad_mem(target, first_accumulates):
             ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
-                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=dmem, ldc=dm, c_strides=(Sk * dm, 0))
+                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
+                     accumulate=first_accumulates)
             ops.gemm(dS, Qp, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
-                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=dmem, ldc=dm, c_strides=(Sk * dm, 0),
+                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
                      accumulate=True)
+        dmem = None
+        if need[1] and not self_att:
+            dmem = torch.empty(B, Sk, dm, device=dev)
+            grad_mem(dmem, False)
         # scores = scale * Q'_h mem^T (scale is already inside dS)
         dQp = zeros(rows, H * dmp, dtype=_BF16, device=dev)
         ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
@@ -611,6 +637,8 @@ class MemAttnFn(torch.autograd.Function):
         # Q projection and LayerNorm
         dxn = torch.empty(rows, dq, device=dev)
         dwq, _ = _linear_bwd(dQb, D, rows, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=False, need_dx=True, dx_f32=dxn)
+        if self_att:
+            grad_mem(dxn, True)        # the keys / values are LN(x) too: their gradient joins the query path's
         dx = torch.empty(B, L, dq, device=dev)
         dlnw = SCRATCH.f32(dq, device=dev) if need[2] else None
         dlnb = SCRATCH.f32(dq, device=dev) if need[3] else None

@@ -69,13 +69,30 @@ class BMEncoderLayer(nn.Module):
             cls._side = torch.cuda.Stream(device=device)
         return torch.cuda.current_stream(), cls._side
 
+    # Attentions whose keys / values are rows narrower than a head (the 128-wide audio stream against d_k = 256) run in
+    # the absorbed-projection form (functional.MemAttnFn): scores_h = (Q_h Wk_h) A^T, context_h = P_h A -- one key /
+    # value tile for all heads, half the attention FLOPs, no K|V projection of the 12 800 audio rows.
+    absorb_narrow_memory = True
+
+    def _self_att_M2(self, M2, M2_mask):
+        att, norm = self.self_att_M2, self.res_layers_M2[0].norm
+        if self.absorb_narrow_memory and M2.is_cuda and att.d_model_K < att.d_k:
+            return att.fused_memory(M2, None, M2_mask, norm)
+        return att.fused(M2, None, M2_mask, norm, residual=True)
+
+    def _cross_M1(self, M1, M2, M2_mask):
+        att, norm = self.bi_modal_att_M1, self.res_layers_M1[1].norm
+        if self.absorb_narrow_memory and M1.is_cuda and att.d_model_K < att.d_k:
+            return att.fused_memory(M1, M2, M2_mask, norm)
+        return att.fused(M1, M2, M2_mask, norm, residual=True)
+
     def forward(self, x, masks):
         M1, M2 = x
         M1_mask, M2_mask = masks
         if not (M1.is_cuda and self.modality_side_stream):
             M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
-            M2 = self.self_att_M2.fused(M2, None, M2_mask, self.res_layers_M2[0].norm, residual=True)
-            M1m2 = self.bi_modal_att_M1.fused(M1, M2, M2_mask, self.res_layers_M1[1].norm, residual=True)
+            M2 = self._self_att_M2(M2, M2_mask)
+            M1m2 = self._cross_M1(M1, M2, M2_mask)
             M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
             M1m2 = self.feed_forward_M1.fused(M1m2, self.res_layers_M1[2].norm)
             M2m1 = self.feed_forward_M2.fused(M2m1, self.res_layers_M2[2].norm)
@@ -83,14 +100,14 @@ class BMEncoderLayer(nn.Module):
         main, side = self._fork(M1.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            M2 = self.self_att_M2.fused(M2, None, M2_mask, self.res_layers_M2[0].norm, residual=True)
+            M2 = self._self_att_M2(M2, M2_mask)
         M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
         main.wait_stream(side)          # both self-attention outputs are needed by both cross attentions
         side.wait_stream(main)
         with torch.cuda.stream(side):
             M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
             M2m1 = self.feed_forward_M2.fused(M2m1, self.res_layers_M2[2].norm)
-        M1m2 = self.bi_modal_att_M1.fused(M1, M2, M2_mask, self.res_layers_M1[1].norm, residual=True)
+        M1m2 = self._cross_M1(M1, M2, M2_mask)
         M1m2 = self.feed_forward_M1.fused(M1m2, self.res_layers_M1[2].norm)
         main.wait_stream(side)
         return M1m2, M2m1

@@ -41,7 +41,7 @@ class MultiheadedAttention(nn.Module):
         """x + drop(MHA(LN(x), mem, mem)) for few queries against a long memory: same function as fused(x, mem, ...,
         residual=True), evaluated without ever projecting the memory (functional.MemAttnFn)."""
         p = self.dout_p if self.training else 0.0
-        return MemAttnFn.apply(x, mem, norm.weight, norm.bias, *self._params(), mask, self.H, p)
+        return MemAttnFn.apply(x, mem, norm.weight, norm.bias, *self._params(), mask, self.H, p)   # mem None: self attention
 
     def forward(self, Q, K, V, mask, causal=False):
         """Reference signature: Q (B,Sq,Dq), K (B,Sk,Dk), V (B,Sk,Dv), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).

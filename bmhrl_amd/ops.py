@@ -77,6 +77,14 @@ def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq
                                                dropout_p, seed, _p(seed_dev), stream()), "bmhrl_attention_fwd")
 
 
+def attention_shared128_fwd(Qp, X, ctx, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, ldq, ldx, ldo):
+    """absorbed-projection attention: Qp (B,Sq,H,128), X (B,Sk,128) shared by all heads -> ctx (B,Sq,H,128)"""
+    _need_cuda(Qp, X, ctx)
+    _lib.check(_lib.load().bmhrl_attention_shared128_fwd(Qp.data_ptr(), ldq, X.data_ptr(), ldx, ctx.data_ptr(), ldo,
+                                                         row_max.data_ptr(), row_sum.data_ptr(), _p(mask), mask_sb,
+                                                         B, H, Sq, Sk, scale, stream()), "bmhrl_attention_shared128_fwd")
+
+
 def softmax_rows(S, lds, P, ldp, rows, cols):
     _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr(), ldp, rows, cols, stream()), "bmhrl_softmax_rows")
 

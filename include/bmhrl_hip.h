@@ -84,6 +84,16 @@ int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, 
                         int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t DK, float scale,
                         float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
 
+/* The same attention in the absorbed-projection form for keys / values that are 128 wide before their projection (the
+ * audio stream): scores_h = scale * Qp_h X^T with Qp_h = Q_h Wk_h (B,Sq,H,128), context_h = softmax(scores_h) X --
+ * X (B,Sk,128) serves every head as keys and values; Q_h K_h^T differs from Qp_h X^T only by a per-row constant, and
+ * P_h V_h = context_h Wv_h^T + bv_h (model/multihead_attention.py:7-31 with K = X Wk^T + bk, V = X Wv^T + bv).
+ * ctx (B,Sq,H,128) bf16, normalised, no dropout (it applies after the Wv projection).  mask: (B,Sk) bytes or NULL.
+ * row_max / row_sum as bmhrl_attention_fwd.  Sk <= 1024. */
+int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo,
+                                  float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
+                                  int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale, bmhrl_stream_t stream);
+
 /* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
  * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */
 int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,

@@ -26,3 +26,20 @@ gaps = sorted(((seg[i + 1][0] - max(x[1] for x in seg[:i + 1][-8:]), seg[i][2][:
 print("largest gaps (us, after kernel -> before kernel):")
 for g, a, b in gaps[:12]:
     print(f"  {g / 1e3:8.1f}  {a}  ->  {b}")
+
+# per-queue busy time and the top kernels of the busiest queue (the critical path of the captured graph)
+import collections
+qs = collections.defaultdict(list)
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if s >= t0 and e <= t1:
+        qs[r["Queue_Id"]].append((s, e, r["Kernel_Name"]))
+print("per queue: kernels, busy ms/step")
+for q, v in sorted(qs.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+    print(f"  queue {q}: {len(v) / steps:.0f} kernels/step, {sum(e - s for s, e, _ in v) / steps / 1e6:.3f} ms/step")
+q0 = max(qs.items(), key=lambda kv: sum(e - s for s, e, _ in kv[1]))[1]
+agg = collections.defaultdict(float)
+for s, e, n in q0:
+    agg[n.split("(")[0][-60:]] += (e - s) / steps / 1e6
+for n, v in sorted(agg.items(), key=lambda kv: -kv[1])[:12]:
+    print(f"    {v:.3f} ms/step  {n}")

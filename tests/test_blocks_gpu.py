@@ -274,3 +274,55 @@ def test_memory_attention_matches_projected_form(B, L, Sk, dq, dm, D, H):
             assert float(g0[k].abs().max()) < 1e-2 * float(g0["linear_Q2d.bias"].abs().max())
         else:
             assert rl2(g1[k], g0[k]) < 1.5e-2, k
+
+
+@pytest.mark.parametrize("kind,B,L,Sk,dq", [("cross", 2, 256, 800, 1024), ("cross", 1, 130, 70, 300), ("self", 2, 800, 800, 128),
+                                            ("self", 2, 200, 200, 128)])
+def test_absorbed_attention_fused_128_path(kind, B, L, Sk, dq):
+    """MemAttnFn with the fused head-dim-128 kernel (audio rows as keys / values, many queries) and its self-attention
+    variant (memory = LN(x)) against MHAFn: outputs, input gradients and every parameter gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import synthetic as syn
+    from bmhrl_amd.model.multihead_attention import MultiheadedAttention
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(L + Sk)
+    dm, D, H = 128, 1024, 4
+    m = MultiheadedAttention(dq, dm, dm, H, 0.0, D)
+    m.load_state_dict(syn.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=13))
+    m = m.to(dev).train()
+    norm = torch.nn.LayerNorm(dq).to(dev)
+    x0 = torch.randn(B, L, dq, generator=g).to(dev)
+    mem0 = torch.randn(B, Sk, dm, generator=g).to(dev)
+    mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=dev)
+    mask[0, 0, Sk - 7:] = False
+    w = torch.randn(B, L, dq, generator=g).to(dev)
+
+    def run(fn):
+        for p in list(m.parameters()) + list(norm.parameters()):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        mem = mem0.clone().requires_grad_(True)
+        y = fn(x, mem)
+        (y * w).sum().backward()
+        grads = {n: p.grad.clone() for n, p in list(m.named_parameters()) + [("ln." + k, v) for k, v in norm.named_parameters()]}
+        return y.detach(), x.grad.clone(), (mem.grad.clone() if mem.grad is not None else None), grads
+
+    if kind == "cross":
+        ref = run(lambda x, mem: m.fused(x, mem, mask, norm, residual=True))
+        got = run(lambda x, mem: m.fused_memory(x, mem, mask, norm))
+    else:
+        ref = run(lambda x, mem: m.fused(x, None, mask, norm, residual=True))
+        got = run(lambda x, mem: m.fused_memory(x, None, mask, norm))
+
+    def rl2(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+    assert float((got[0] - ref[0]).abs().max() / ref[0].abs().max()) < 5e-3
+    assert rl2(got[1], ref[1]) < 1.5e-2
+    if kind == "cross":
+        assert rl2(got[2], ref[2]) < 1.5e-2
+    for k in ref[3]:
+        if k == "linear_K2d.bias":
+            assert float(got[3][k].abs().max()) == 0.0
+        else:
+            assert rl2(got[3][k], ref[3][k]) < 1.5e-2, k
