@@ -44,40 +44,64 @@ def parse():
     return ap.parse_args()
 
 
-def attention_roofline(dev, B, H, Sq, Sk, iters=50):
-    """Mean launch time of the fused cross-modal attention kernel at the step's own shape, HIP events on torch's
-    current stream (the stream the kernel is launched on)."""
-    from bmhrl_amd import ops
-    dk, D = 256, H * 256
-    g = torch.Generator(device="cpu").manual_seed(0)
-    Q = torch.randn(B, Sq, D, generator=g).to(dev).to(torch.bfloat16)
-    K = torch.randn(B, Sk, D, generator=g).to(dev).to(torch.bfloat16)
-    V = torch.randn(B, Sk, D, generator=g).to(dev).to(torch.bfloat16)
-    mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=dev)
-    O = torch.empty(B, Sq, D, dtype=torch.bfloat16, device=dev)
-    rmax = torch.empty(B, H, Sq, device=dev)
-    rsum = torch.empty(B, H, Sq, device=dev)
-    run = lambda: ops.attention_fwd(Q, K, V, O, rmax, rsum, mask, Sk, 0, B, H, Sq, Sk, dk, dk ** -0.5, D, D, D, D)
+def _time_launches(fn, iters):
     for _ in range(5):
-        run()
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        run()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
-    flops = 4.0 * B * Sq * Sk * D
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def attention_roofline(dev, B, H, Sq, Sk, iters=50):
+    """Mean launch time of the kernel that computes the cross-modal video<-audio attention of a step, at the step's own
+    shape, HIP events on torch's current stream (the stream the kernel is launched on).
+
+    Since r01 that attention runs in the absorbed-projection form: keys / values are the 128-wide
+    audio rows themselves, shared by all heads, and the d_model-wide K / V projections act on the query side.
+    `achieved` follows the contract: ALGORITHMIC flops of the attention call it replaces (4*B*Sq*Sk*D with
+    D = H*d_k = 1024) over the launch time; the flops the kernel actually executes (half of that) and the two small
+    GEMMs the form adds next to it (Q_h Wk_h before, context Wv_h^T after) are reported alongside."""
+    from bmhrl_amd import ops
+    dk, D, dm = 256, H * 256, 128
+    g = torch.Generator(device="cpu").manual_seed(0)
+    Qp = (0.5 * torch.randn(B, Sq, H, dm, generator=g)).to(dev).to(torch.bfloat16)
+    X = torch.randn(B, Sk, dm, generator=g).to(dev).to(torch.bfloat16)
+    mask = torch.ones(B, Sk, dtype=torch.bool, device=dev)
+    ctx = torch.empty(B, Sq, H, dm, dtype=torch.bfloat16, device=dev)
+    rmax = torch.empty(B, H, Sq, device=dev)
+    rsum = torch.empty(B, H, Sq, device=dev)
+    sec = _time_launches(lambda: ops.attention_shared128_fwd(Qp, X, ctx, rmax, rsum, mask, Sk, B, H, Sq, Sk, dk ** -0.5,
+                                                             H * dm, dm, H * dm), iters)
+    # the two GEMMs the absorbed form adds around the kernel (it removes the 2*B*Sk*128*2048-flop K|V projection)
+    rows = B * Sq
+    Qb = torch.randn(rows, D, generator=g).to(dev).to(torch.bfloat16)
+    Wk = torch.randn(D, dm, generator=g).to(dev).to(torch.bfloat16)
+    Ob = torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
+    Qp2 = Qp.view(rows, H * dm)
+    sec_q = _time_launches(lambda: ops.gemm(Qb, Wk, rows, dm, dk, lda=D, ldb=dm, b_trans=True, batch=(1, H), a_strides=(0, dk),
+                                            b_strides=(0, dk * dm), C_bf16=Qp2, ldcb=H * dm, cb_strides=(0, dm)), iters)
+    sec_o = _time_launches(lambda: ops.gemm(Qp2, Wk, rows, dk, dm, lda=H * dm, ldb=dm, batch=(1, H), a_strides=(0, dm),
+                                            b_strides=(0, dk * dm), C_bf16=Ob, ldcb=D, cb_strides=(0, dk)), iters)
+    flops = 4.0 * B * Sq * Sk * D               # the attention call this launch stands for (SURVEY 8d)
+    executed = 4.0 * B * H * Sq * Sk * dm
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
     tj = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
     if os.path.exists(tj):
         t = json.load(open(tj))
         if t["shape"] == {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}:
             traffic = t["traffic_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel (cross-modal V<-A)", "achieved": flops / sec / 1e12,
-            "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0, "traffic": traffic,
-            "launch_us": sec * 1e6, "flops_per_launch": flops,
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel<128> (cross-modal V<-A, absorbed-projection form: the 128-wide "
+                                       "audio rows are keys and values of all heads)",
+            "achieved": flops / sec / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0,
+            "traffic": traffic, "launch_us": sec * 1e6, "flops_per_launch": flops,
+            "executed_flops_per_launch": executed, "executed_tflops": executed / sec / 1e12,
+            "executed_frac": executed / sec / 1e12 / 2500.0,
+            "adjacent_launches_us": {"Q_h Wk_h (2*B*Sq*D*128 flops)": sec_q * 1e6, "context Wv_h^T (same)": sec_o * 1e6},
             "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}}
 
 

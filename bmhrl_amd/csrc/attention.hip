@@ -114,7 +114,13 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the q-tiles of one (b, head)
   // -- which stream the same K/V -- are given block ids that differ by multiples of 8 and thus share an L2.
   int bh, qt;
-  if ((p.B * p.H) % 8 == 0) {
+  if (p.k_hs == 0 && p.B % 8 == 0) {
+    // one key / value tile for all heads: every (head, q-tile) of a batch row goes to the same XCD
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per_b = p.H * p.q_tiles;
+    bh = (xcd + 8 * (idx / per_b)) * p.H + (idx % per_b) / p.q_tiles;
+    qt = idx % p.q_tiles;
+  } else if ((p.B * p.H) % 8 == 0) {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bh = xcd + 8 * (idx / p.q_tiles);
     qt = idx % p.q_tiles;

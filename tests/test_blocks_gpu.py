@@ -2,6 +2,7 @@
 block written with plain torch fp32 ops and autograd on bf16-rounded weights.  Medium sizes, so bf16 rounding noise
 averages out: tolerance 1e-2 on every gradient (max|a-b| / max|ref|), 5e-3 on outputs."""
 import math
+import zlib
 
 import pytest
 import torch
@@ -52,7 +53,7 @@ def ref_mha(x, kv, ln, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, residual):
 @pytest.mark.parametrize("case", ["self_flash", "cross_flash", "self_mat", "cross_mat", "goal"])
 def test_mha_block(dev, case):
     from bmhrl_amd.functional import MHAFn
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(case.encode()) % 1000)   # (str hashes change from process to process)
     B = 2
     if case == "self_flash":
         dq = dkv = 128; D, H, Sq, Sk = 1024, 4, 200, 200; cross = False; ln = True; res = True
