@@ -76,13 +76,13 @@ class BMEncoderLayer(nn.Module):
 
     def _self_att_M2(self, M2, M2_mask):
         att, norm = self.self_att_M2, self.res_layers_M2[0].norm
-        if self.absorb_narrow_memory and M2.is_cuda and att.d_model_K < att.d_k:
+        if self.absorb_narrow_memory and M2.is_cuda and att.d_model_K == 128 and att.d_k > 128:   # (the fused kernel's width)
             return att.fused_memory(M2, None, M2_mask, norm)
         return att.fused(M2, None, M2_mask, norm, residual=True)
 
     def _cross_M1(self, M1, M2, M2_mask):
         att, norm = self.bi_modal_att_M1, self.res_layers_M1[1].norm
-        if self.absorb_narrow_memory and M1.is_cuda and att.d_model_K < att.d_k:
+        if self.absorb_narrow_memory and M1.is_cuda and att.d_model_K == 128 and att.d_k > 128:
             return att.fused_memory(M1, M2, M2_mask, norm)
         return att.fused(M1, M2, M2_mask, norm, residual=True)
 
