@@ -38,6 +38,60 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
   }
 }
 
+// Same, D % 4 == 0 and aligned: the row is read once with 16-byte loads and kept in registers (NV groups of 4 columns per
+// lane), mean / variance come from the registers, the bf16 output leaves as 8-byte stores.
+template <int NV>
+__global__ void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  bf16_t* __restrict__ yb, long ldy, float* __restrict__ yf, float* __restrict__ mean,
+                                  float* __restrict__ rstd, long rows, int D) {
+  const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * D;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    v[i] = c < D ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mu;
+        q += d * d;
+      }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + 1e-5f);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < D) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 y;
+      bf16x4 yo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+        yo[j] = (bf16_t)y[j];
+      }
+      if (yb) *reinterpret_cast<bf16x4*>(yb + row * ldy + c) = yo;
+      if (yf) *reinterpret_cast<f32x4*>(yf + row * D + c) = y;
+    }
+  }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.  Each wave walks `rows_per_wave` rows and keeps
 // its lanes' dgamma/dbeta partial sums in registers (<= 16 columns per lane, D <= 1024), then one atomic per column.
 constexpr int LN_MAXC = 16;
@@ -455,6 +509,16 @@ extern "C" int bmhrl_layernorm_fwd(const float* x, const float* gamma, const flo
                                    float* y_f32, float* mean, float* rstd, int64_t rows, int32_t D, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32) && rows > 0 && D > 0);
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+  const bool vec = D % 4 == 0 && D <= 1024 && ldy % 4 == 0 &&
+                   ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_f32) & 15) == 0) && (((uintptr_t)y_bf16 & 7) == 0);
+  if (vec) {
+    const int nv = (D + 255) / 256;
+#define LN_FWDV(NV_) hipLaunchKernelGGL(ln_fwd_vec_kernel<NV_>, grid, block, 0, S_(stream), x, gamma, beta, (bf16_t*)y_bf16, \
+                                        (long)ldy, y_f32, mean, rstd, (long)rows, D)
+    if (nv <= 1) LN_FWDV(1); else if (nv <= 2) LN_FWDV(2); else LN_FWDV(4);
+#undef LN_FWDV
+    return hip_status(hipGetLastError());
+  }
   hipLaunchKernelGGL(ln_fwd_kernel, grid, block, 0, S_(stream), x, gamma, beta, (bf16_t*)y_bf16, (long)ldy, y_f32, mean,
                      rstd, (long)rows, D);
   return hip_status(hipGetLastError());
