@@ -479,3 +479,81 @@ def detr_stack(sd: SD, p: str, n_layers: int, x: Tensor, layer_fn, has_norm: boo
         x = layer_norm(sd, p + ".norm", x)
         inter[-1] = layer_norm(sd, p + ".norm", x)
     return torch.stack(inter) if return_intermediate else x
+
+
+# --------------------------------------------------------------------------------------
+# host-side RL glue of the reference, restated as the loops they are
+# discontinue_reward_loop is pinned to the reference's own function (tests/golden/rl_glue.npz: metrics/util.py loads
+# without nltk); the two segment loops sit in modules that import nltk and are pinned by reading only.
+# --------------------------------------------------------------------------------------
+def manager_segment_loop(sampled_probs: Tensor, expected_scores: Tensor, segments: Tensor) -> Tuple[Tensor, Tensor]:
+    """epoch_loops/captioning_bmrl_loops.py:301-316 (manager branch of biased_kl): per segment (positions after the
+    previous segment end up to and including a marked position) the product of the sampled probabilities and the sum of
+    the expected scores, written over the whole segment.  When the loop moves on to a later batch row, the tail of the
+    row it leaves (after its last segment end) is zeroed in both tensors -- the initial `old_b = 0` makes that row 0,
+    from position 0, when row 0 has no segment; the last row with segments keeps its tail.
+    Returns (segment_prob, expected_scores'); expected_scores is not modified in place here."""
+    B, L = sampled_probs.shape
+    es = expected_scores.clone()
+    sp = torch.zeros(B, L, dtype=torch.float32)
+    old_l = old_b = 0
+    for b, l in torch.nonzero(segments).tolist():
+        if b != old_b:
+            es[old_b, old_l:] = 0
+            sp[old_b, old_l:] = 0
+            old_b, old_l = b, 0
+        sp[b, old_l:l + 1] = torch.prod(sampled_probs[b, old_l:l + 1])
+        es[b, old_l:l + 1] = torch.sum(es[b, old_l:l + 1])
+        old_l = l + 1
+    return sp, es
+
+
+def segment_reward_loop(reward: Tensor, sections: Tensor) -> Tuple[Tensor, Tensor]:
+    """metrics/batched_meteor.py:19-36: every segment gets the sum of its rewards on all of its positions, positions
+    behind the last segment end stay 0.  Returns (segment_reward, segment_indices)."""
+    B, L = reward.shape
+    out = torch.zeros(B, L, dtype=torch.float32)
+    idx = torch.nonzero(sections)
+    old_l = old_b = 0
+    for b, l in idx.tolist():
+        if b != old_b:
+            out[b, old_l:] = 0
+            old_b, old_l = b, 0
+        out[b, old_l:l + 1] = torch.sum(reward[b, old_l:l + 1])
+        old_l = l + 1
+    return out, idx
+
+
+def discontinue_reward_loop(cider_diff: Tensor, gamma: float, n_step: int = 100, segments: Optional[Tensor] = None) -> Tensor:
+    """metrics/util.py:53-88.  Without segments: discounted return over at most n_step following positions.  With
+    segments: the reward of a segment end plus the discounted rewards of the later segment ends of its row is written
+    over the segment -- but the reference guards the accumulation with `i < segment_idx.shape[0]` (== 2, the width of one
+    index pair), so only the first two segment ends of the whole batch see later rewards; kept.  On a row change the
+    tail of the row left behind is zeroed; the last row keeps its tail."""
+    if segments is None:
+        B, L = cider_diff.shape
+        out = torch.zeros(B, L, dtype=torch.float32)
+        for b in range(B):
+            for t in range(L):
+                acc = 0.0
+                for i in range(min(n_step, L - t)):
+                    acc = acc + (gamma ** i) * float(cider_diff[b, t + i])
+                out[b, t] = acc
+        return out
+    cd = cider_diff.clone()
+    idx = torch.nonzero(segments).tolist()
+    old_l = old_b = 0
+    for i, (b, l) in enumerate(idx):
+        disc = cd[b, l].clone()
+        if old_b != b:
+            cd[old_b, old_l:] = 0
+            old_l, old_b = 0, b
+        if i < 2:
+            for n, (b2, l2) in enumerate(idx[i + 1:]):
+                if b == b2:
+                    disc = disc + (gamma ** (n + 1)) * cd[b2, l2]
+                else:
+                    break
+        cd[b, old_l:l + 1] = disc
+        old_l = l + 1
+    return cd

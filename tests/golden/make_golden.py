@@ -297,6 +297,34 @@ def detr_cases():
     np.savez_compressed(os.path.join(HERE, "detr.npz"), **out)
 
 
+def rl_glue_cases():
+    """metrics/util.py:discontinue_reward (the file imports only torch, so it is loaded by path; its package pulls nltk).
+    The segment loops of metrics/batched_meteor.py and epoch_loops/captioning_bmrl_loops.py import nltk at module level
+    and cannot be executed here: their restatements in oracle/ are pinned by reading only."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_metrics_util", os.path.join(REF, "metrics", "util.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    g = torch.Generator().manual_seed(17)
+    out = {}
+    n = 0
+    for i in range(24):
+        B = int(torch.randint(1, 6, (1,), generator=g))
+        L = int(torch.randint(2, 13, (1,), generator=g))
+        x = torch.randn(B, L, generator=g)
+        seg = (torch.rand(B, L, generator=g) < 0.35).int()
+        if i % 5 == 0:
+            seg[0] = 0
+        gamma = 0.5 + 0.45 * float(torch.rand(1, generator=g))
+        n_step = [100, 3, 1][i % 3]
+        out[f"x{i}"], out[f"seg{i}"], out[f"par{i}"] = np_(x), np_(seg), np.array([gamma, n_step])
+        out[f"plain{i}"] = np_(ref.discontinue_reward(x.clone(), gamma, n_step).float())
+        out[f"segd{i}"] = np_(ref.discontinue_reward(x.clone(), gamma, n_step, seg))
+        n += 1
+    out["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "rl_glue.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -307,6 +335,7 @@ if __name__ == "__main__":
     agent_tiny()
     sample_clip_decode()
     detr_cases()
+    rl_glue_cases()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

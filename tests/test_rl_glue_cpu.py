@@ -1,0 +1,65 @@
+"""Vectorised RL glue (bmhrl_amd/rl_glue.py) against the loop restatements of the reference in oracle/ (CPU)."""
+import pytest
+import torch
+
+from bmhrl_amd import rl_glue as G
+from oracle import bmhrl_oracle as O
+
+
+def _cases(n=60):
+    g = torch.Generator().manual_seed(0)
+    for i in range(n):
+        B = int(torch.randint(1, 6, (1,), generator=g))
+        L = int(torch.randint(2, 13, (1,), generator=g))
+        dens = float(torch.rand(1, generator=g)) * 0.6
+        seg = (torch.rand(B, L, generator=g) < dens).int()
+        if i % 7 == 0:
+            seg[0] = 0                      # row 0 without a segment: the `old_b = 0` quirk
+        if i % 11 == 0:
+            seg[:] = 0
+        yield g, B, L, seg
+
+
+def test_manager_segments():
+    for g, B, L, seg in _cases():
+        p = torch.rand(B, L, generator=g) * 0.9 + 0.05
+        es = torch.randn(B, L, generator=g)
+        sp0, es0 = O.manager_segment_loop(p, es, seg)
+        sp1, es1 = G.manager_segments(p, es, seg)
+        assert torch.allclose(sp1, sp0, rtol=1e-5, atol=1e-7), (seg, sp0, sp1)
+        assert torch.allclose(es1, es0, rtol=1e-5, atol=1e-6), (seg, es0, es1)
+
+
+def test_segment_reward():
+    for g, B, L, seg in _cases():
+        r = torch.randn(B, L, generator=g)
+        a0, i0 = O.segment_reward_loop(r, seg)
+        a1, i1 = G.segment_reward(r, seg)
+        assert torch.allclose(a1, a0, rtol=1e-5, atol=1e-6) and torch.equal(i0, i1)
+
+
+@pytest.mark.parametrize("n_step", [100, 3, 1])
+def test_discounted_returns_without_segments(n_step):
+    for g, B, L, _ in _cases(20):
+        x = torch.randn(B, L, generator=g)
+        assert torch.allclose(G.discontinue_reward(x, 0.9, n_step), O.discontinue_reward_loop(x, 0.9, n_step), rtol=1e-5, atol=1e-6)
+
+
+def test_discontinue_reward_with_segments():
+    for g, B, L, seg in _cases():
+        x = torch.randn(B, L, generator=g)
+        a0 = O.discontinue_reward_loop(x, 0.8, 100, seg)
+        a1 = G.discontinue_reward(x, 0.8, 100, seg)
+        assert torch.allclose(a1, a0, rtol=1e-5, atol=1e-6), (seg, x, a0, a1)
+
+
+def test_discontinue_reward_oracle_and_vectorised_match_reference_fixture(golden):
+    """tests/golden/rl_glue.npz was produced by the reference's own metrics/util.py:discontinue_reward."""
+    g = golden("rl_glue")
+    T = torch.from_numpy
+    for i in range(int(g["n"])):
+        x, seg = T(g[f"x{i}"]), T(g[f"seg{i}"])
+        gamma, n_step = float(g[f"par{i}"][0]), int(g[f"par{i}"][1])
+        for fn in (O.discontinue_reward_loop, G.discontinue_reward):
+            assert torch.allclose(fn(x.clone(), gamma, n_step), T(g[f"plain{i}"]), rtol=1e-5, atol=1e-6), (fn, i)
+            assert torch.allclose(fn(x.clone(), gamma, n_step, seg), T(g[f"segd{i}"]), rtol=1e-5, atol=1e-6), (fn, i)
