@@ -162,11 +162,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal aid for the multi-rank path on a one-GPU box: BMHRL_BENCH_BACKEND=gloo BMHRL_BENCH_ONE_DEVICE=1 runs every
+    # rank on cuda:0 with gloo collectives (RCCL refuses two ranks on one device); never used by the driver
+    backend = os.environ.get("BMHRL_BENCH_BACKEND", "nccl")
+    if os.environ.get("BMHRL_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from bmhrl_amd import _lib, synthetic as syn

@@ -193,7 +193,7 @@ class CaptionTrainer:
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._graph_body_a()
-                self._graph_body_b(1.0)
+                self._graph_body_b(self.opt.all_reduce())   # warm-up steps are real steps: replicas stay identical
             SHADOWS.refresh()                 # builds the segment table of the one-launch shadow refresh (a host -> device
                                               # copy, not allowed while capturing); the captured body reuses it
         torch.cuda.current_stream().wait_stream(s)
