@@ -53,12 +53,19 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
 
-    def gather_grads(self):
+    def set_split(self, n_early: int):
+        """the first n_early parameters form bucket 0 (their gradients are complete early in backward), the rest bucket 1"""
+        self.n_early = n_early
+        self.split_off = self.offsets[n_early] if n_early < len(self.params) else self.n
+
+    def gather_grads(self, part=None):
         """copy the autograd gradients into the flat bucket; missing ones stay zero.  On the GPU this is ONE launch of the
         segmented copy kernel (bmhrl_cast_segments, fp32 mode): inside a trainer step the gradients live at fixed
-        addresses (slices of the step scratch arena), so the segment table is built once and reused."""
+        addresses (slices of the step scratch arena), so the segment table is built once and reused.
+        part: None = all parameters, 0 / 1 = one of the two buckets of set_split()."""
         dst, src, missing = [], [], []
-        for p, gv in zip(self.params, self.grad_views):
+        lo, hi = (0, len(self.params)) if part is None else ((0, self.n_early) if part == 0 else (self.n_early, len(self.params)))
+        for p, gv in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             if p.grad is None:
                 missing.append(gv)
             else:
@@ -72,7 +79,8 @@ class FlatAdam:
             torch._foreach_copy_(dst, src)
             return
         sig = tuple((g.data_ptr(), d.data_ptr(), g.numel()) for g, d in zip(src, dst))
-        if getattr(self, "_gather_sig", None) != sig:
+        plans = self.__dict__.setdefault("_gather_plans", {})
+        if plans.get(part, (None,))[0] != sig:
             if torch.cuda.is_current_stream_capturing():      # (cannot upload a table now; capture() warms this up first)
                 torch._foreach_copy_(dst, src)
                 return
@@ -80,9 +88,8 @@ class FlatAdam:
             for sp, dp, n in sig:
                 rows.append([sp, dp, 1, n, 0, blk])
                 blk += (n + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
-            self._gather_plan = (torch.tensor(rows, dtype=torch.int64).to(self.flat.device), len(rows), blk)
-            self._gather_sig = sig
-        table, n_seg, n_blk = self._gather_plan
+            plans[part] = (sig, torch.tensor(rows, dtype=torch.int64).to(self.flat.device), len(rows), blk)
+        _, table, n_seg, n_blk = plans[part]
         ops.cast_segments(table, n_seg, n_blk)
 
     def all_reduce(self, group=None):
@@ -90,6 +97,14 @@ class FlatAdam:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
             return 1.0 / dist.get_world_size(group)
         return 1.0
+
+    def all_reduce_part(self, part: int, group=None):
+        """asynchronous all-reduce (sum) of one bucket of set_split(); returns the work handle (None without a group)"""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            lo, hi = (0, self.split_off) if part == 0 else (self.split_off, self.n)
+            if hi > lo:
+                return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return None
 
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
@@ -144,7 +159,18 @@ class CaptionTrainer:
         self.pad_idx = pad_idx
         self.criterion = LabelSmoothing(smoothing, pad_idx)
         self.rl_criterion = BiasedKL(smoothing, pad_idx)
-        self.opt = FlatAdam(trainable_bucket(self.agent), lr=lr, weight_decay=weight_decay)
+        # bucket order: everything but the encoder first.  Backward reaches the encoder last, so in data-parallel runs the
+        # all-reduce of the first bucket overlaps the encoder's backward (split_backward).
+        names = {id(p): n for n, p in self.agent.named_parameters()}
+        bucket = trainable_bucket(self.agent)
+        early = [p for p in bucket if not names[id(p)].startswith("bm_enc.")]
+        late = [p for p in bucket if names[id(p)].startswith("bm_enc.")]
+        self.opt = FlatAdam(early + late, lr=lr, weight_decay=weight_decay)
+        self.opt.set_split(len(early))
+        self.early_params, self.late_params = early, late
+        self.split_backward = None          # None: split when a process group with more than one rank is active
+        self._enc_out = None
+        self.agent.bm_enc.register_forward_hook(lambda mod, inp, out: setattr(self, "_enc_out", out))
         self.modality = "audio_video"
         self.graph = None
         self.static = None
@@ -193,6 +219,8 @@ class CaptionTrainer:
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._graph_body_a()
+                if self._split():
+                    self._graph_body_a2()
                 self._graph_body_b(self.opt.all_reduce())   # warm-up steps are real steps: replicas stay identical
             SHADOWS.refresh()                 # builds the segment table of the one-launch shadow refresh (a host -> device
                                               # copy, not allowed while capturing); the captured body reuses it
@@ -201,6 +229,10 @@ class CaptionTrainer:
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self._graph_body_a()
+        if self._split():
+            self.graph_a2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool()):
+                self._graph_body_a2()
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
             self._graph_body_b(self._world_scale())
@@ -209,6 +241,14 @@ class CaptionTrainer:
     @staticmethod
     def _world_scale():
         return 1.0 / dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1.0
+
+    def _split(self) -> bool:
+        if self.split_backward is None:
+            import os
+            if os.environ.get("BMHRL_SPLIT_BACKWARD") in ("0", "1"):      # tuning / rehearsal override
+                return os.environ["BMHRL_SPLIT_BACKWARD"] == "1"
+            return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return bool(self.split_backward)
 
     def _graph_body_a(self):
         st = self.static
@@ -220,10 +260,28 @@ class CaptionTrainer:
         SHADOWS.invalidate()
         SHADOWS.refresh()
         loss, _ = self._forward_loss(st, trg_in, trg_y)
-        loss.backward()
-        self.opt.gather_grads()
-        SCRATCH.end_step()
+        if self._split():
+            # phase 1 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)
+            enc_out = list(self._enc_out)
+            outs = torch.autograd.grad(loss, self.early_params + enc_out, retain_graph=True, allow_unused=True)
+            for p, g in zip(self.early_params, outs):
+                p.grad = g
+            self._enc_grads = (enc_out, list(outs[len(self.early_params):]))
+            self.opt.gather_grads(0)
+        else:
+            loss.backward()
+            self.opt.gather_grads()
+            SCRATCH.end_step()
         self.static_loss.copy_(loss.detach())
+
+    def _graph_body_a2(self):
+        """phase 2 of the backward (split mode): the encoder, from the gradients of its two outputs"""
+        enc_out, enc_grads = self._enc_grads
+        pairs = [(t, g) for t, g in zip(enc_out, enc_grads) if g is not None]
+        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs], inputs=self.late_params)
+        self._enc_grads = self._enc_out = None
+        self.opt.gather_grads(1)
+        SCRATCH.end_step()
 
     def _graph_body_b(self, scale):
         self.opt.step(scale)
@@ -234,6 +292,14 @@ class CaptionTrainer:
                 self.static[k].copy_(fs[k])
             self.static["captions"].copy_(captions)
         self.graph_a.replay()
-        self.opt.all_reduce()
+        if self._split():
+            w0 = self.opt.all_reduce_part(0)      # overlaps the encoder backward below
+            self.graph_a2.replay()
+            w1 = self.opt.all_reduce_part(1)
+            for w in (w0, w1):
+                if w is not None:
+                    w.wait()
+        else:
+            self.opt.all_reduce()
         self.graph_b.replay()
         return self.static_loss
