@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tests/bench_one_attn.py > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tests/${BENCH_SCRIPT:-bench_one_attn.py} > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections
