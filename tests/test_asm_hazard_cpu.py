@@ -1,0 +1,78 @@
+"""attention.hip issues its in-loop LDS reads as inline asm with hand-counted `s_waitcnt lgkmcnt` (the compiler would
+otherwise order every LDS read behind all outstanding direct-to-LDS loads).  The compiler does not know those registers
+are in flight, so it must never copy / spill / use one between the read and the wait that covers it.  This test
+compiles the file to gfx950 assembly (hipcc cross-compiles without a GPU) and checks exactly that on both kernels."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from bmhrl_amd import build as B
+
+CSRC = B.CSRC
+
+
+def _regs(text):
+    out = set()
+    for a, b, c in re.findall(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if c:
+            out.add(int(c))
+        else:
+            out.update(range(int(a), int(b) + 1))
+    return out
+
+
+def _early_uses(lines):
+    pending, bad = {}, []
+    for i, l in enumerate(lines):
+        s = l.strip()
+        if not s or s.startswith(";") or s.endswith(":"):
+            continue
+        op = s.split()[0]
+        if op.startswith("ds_read"):
+            for r in _regs(s.split()[1].rstrip(",")):
+                pending[r] = i
+        elif op == "s_waitcnt" and "lgkmcnt" in s:
+            n = int(re.search(r"lgkmcnt\((\d+)\)", s).group(1))
+            if n == 0:
+                pending.clear()
+            else:        # reads return in order: the newest n may still be outstanding
+                order = sorted(set(pending.values()))
+                keep = set(order[-n:])
+                pending = {r: v for r, v in pending.items() if v in keep}
+        elif op in ("s_barrier", "s_endpgm"):
+            pending.clear()
+        else:
+            hit = sorted(r for r in _regs(" ".join(s.split()[1:])) if r in pending)
+            if hit:
+                bad.append((i, s, hit[:4]))
+    return bad
+
+
+def test_no_use_of_asm_loaded_registers_before_their_wait():
+    src = os.path.join(CSRC, "attention.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "attention.s")
+        cmd = [B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src] + \
+            B.EXTRA_FLAGS.get("attention.hip", [])
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        if r.returncode != 0:
+            pytest.fail("hipcc failed:\n" + r.stderr[-2000:])
+        text = open(out).read()
+    kernels = re.findall(r"^(_ZN\S*attn_fwd_kernel\S*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) >= 3                      # <256,true>, <256,false>, <128,false>
+    for name, body in kernels:
+        lines = body.split("\n")
+        assert sum("ds_read_b64_tr_b16" in l for l in lines) >= 16, name
+        bad = _early_uses(lines)
+        assert not bad, (name, bad[:5])
+
+
+def test_checker_flags_an_early_use():
+    hazard = ["ds_read_b64_tr_b16 v[10:11], v2 offset:64", "ds_read_b128 v[12:15], v3",
+              "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v20, v10", "v_mov_b32_e32 v21, v12"]
+    bad = _early_uses(hazard)
+    assert len(bad) == 1 and bad[0][2] == [12]
+    assert not _early_uses(hazard[:2] + ["s_waitcnt lgkmcnt(0)"] + hazard[3:])
