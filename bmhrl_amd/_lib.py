@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbmhrl_hip.so")
+# BMHRL_HIP_LIB: load another build of the same library (kernel A/B comparisons in one run); never a different backend
+LIB_PATH = os.environ.get("BMHRL_HIP_LIB") or os.path.join(_HERE, "csrc", "libbmhrl_hip.so")
 
 i32, i64, u64, f32 = C.c_int32, C.c_int64, C.c_uint64, C.c_float
 ptr = C.c_void_p

@@ -34,6 +34,7 @@
 // of LDS reads (1024 cycles at 128 B/clk) and 64 KiB through the vector memory path (1024 cycles at 64 B/clk) -- the
 // three pipes are balanced, so the kernel is as much LDS/L1-bandwidth bound as MFMA bound.  (Loading K fragments
 // straight from global memory was tried: 32 rows x 32 bytes per load instruction makes it TCP-line-rate bound, slower.)
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -63,7 +64,21 @@ struct AttnArgs {
   long k_hs, v_hs;          // element offset of head h inside a K / V row: h * k_hs (0: one tile for all heads)
   float scale, dropout_p; uint64_t seed; const uint64_t* seed_dev;
   int q_tiles, dbg;
+  // workgroup -> (batch row, head, q-tile) map, chosen on the host; divisions by multiply-high (exact: see div_magic)
+  int map_mode, per_b;
+  unsigned magic_perb, magic_qt, magic_h;
 };
+
+// floor(n / d) == umulhi(n, ceil(2^32 / d)) whenever n * d < 2^32 (d == 1: the magic does not fit, n itself)
+inline unsigned div_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+__device__ __forceinline__ int fast_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+inline void set_block_map(AttnArgs& a) {
+  a.per_b = a.H * a.q_tiles;
+  a.map_mode = (a.k_hs == 0 && a.B % 8 == 0) ? 0 : ((a.B * a.H) % 8 == 0 ? 1 : 2);
+  a.magic_perb = div_magic((unsigned)a.per_b);
+  a.magic_qt = div_magic((unsigned)a.q_tiles);
+  a.magic_h = div_magic((unsigned)a.H);
+}
 
 // LDS reads the compiler must not see (see the header); `addr` is a byte address in LDS.
 template <int OFF>
@@ -78,6 +93,12 @@ __device__ __forceinline__ f32x4 asm_ldsf4(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
+// 16 bytes per lane, global -> LDS; IMM is added to both the global and the LDS address
+template <int IMM>
+__device__ __forceinline__ void glds16(const char* src, bf16_t* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst, 16, IMM, 0);
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -90,6 +111,16 @@ __device__ __forceinline__ float pair_max(float v) {   // max over lanes l and l
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Tuning aid (-DBMHRL_ATTN_TRACE): cycle stamps of wave 0 of the first and the last workgroup at the phase boundaries.
+#ifdef BMHRL_ATTN_TRACE
+__device__ long long g_attn_trace[2][16];
+#define BMHRL_STAMP(i)                                                                                   \
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                              \
+    g_attn_trace[blockIdx.x != 0][i] = (long long)__builtin_readcyclecounter();
+#else
+#define BMHRL_STAMP(i)
+#endif
+
 template <int DK, bool QMASK>
 __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int VST = BN * DK;                // elements of one K or V stage (32 / 16 KiB)
@@ -98,14 +129,17 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   constexpr int OREGS = DK / 2;               // O^T accumulator registers per lane
   constexpr int MERGE_FLOATS = (KW - 1) * QW * (OREGS + 2) * 64;
   static_assert(MERGE_FLOATS * 4 <= LDS_KV, "the merge area reuses the K/V stages");
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_KV + 2 * MAXK * 4];
+  constexpr int MAXT = MAXK / BN;              // key tiles
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_KV + 2 * MAXK * 4 + MAXT * 8];
   float* s_coef = reinterpret_cast<float*>(smem_raw + LDS_KV);
   float* s_pen = s_coef + MAXK;
+  uint64_t* s_slow = reinterpret_cast<uint64_t*>(s_pen + MAXK);   // per tile: lanes (keys) with pen != 0
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   constexpr float RESCALE_THR = 8.f;   // lazy rescale: keep a stale running max while it lags by < 2^8
 
+  BMHRL_STAMP(0)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = wave / KW, ki = wave % KW;
   const int r32 = lane & 31, h = lane >> 5;
@@ -114,21 +148,23 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the q-tiles of one (b, head)
   // -- which stream the same K/V -- are given block ids that differ by multiples of 8 and thus share an L2.
   int bh, qt;
-  if (p.k_hs == 0 && p.B % 8 == 0) {
+  if (p.map_mode == 0) {
     // one key / value tile for all heads: every (head, q-tile) of a batch row goes to the same XCD
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int per_b = p.H * p.q_tiles;
-    bh = (xcd + 8 * (idx / per_b)) * p.H + (idx % per_b) / p.q_tiles;
-    qt = idx % p.q_tiles;
-  } else if ((p.B * p.H) % 8 == 0) {
+    const int q1 = fast_div(idx, p.per_b, p.magic_perb), rem = idx - q1 * p.per_b;
+    const int hq = fast_div(rem, p.q_tiles, p.magic_qt);
+    bh = (xcd + 8 * q1) * p.H + hq;
+    qt = rem - hq * p.q_tiles;
+  } else if (p.map_mode == 1) {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    bh = xcd + 8 * (idx / p.q_tiles);
-    qt = idx % p.q_tiles;
+    const int q1 = fast_div(idx, p.q_tiles, p.magic_qt);
+    bh = xcd + 8 * q1;
+    qt = idx - q1 * p.q_tiles;
   } else {
-    bh = blockIdx.x / p.q_tiles;
-    qt = blockIdx.x % p.q_tiles;
+    bh = fast_div((int)blockIdx.x, p.q_tiles, p.magic_qt);
+    qt = (int)blockIdx.x - bh * p.q_tiles;
   }
-  const int b = bh / p.H, hd = bh % p.H;
+  const int b = fast_div(bh, p.H, p.magic_h), hd = bh - b * p.H;
   const int q_row = qt * (32 * QW) + qi * 32 + r32;       // this lane's query row
   const bool q_ok = q_row < p.Sq;
 
@@ -137,14 +173,72 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
 
   constexpr bool key_mask = !QMASK;    // same mask for every query row (or none) -> LDS coefficients
   const int nt = (p.Sk + BN - 1) / BN;
-  for (int i = tid; i < nt * BN; i += NT) {
-    const bool in = i < p.Sk;
-    bool keep = in;
-    if constexpr (key_mask) keep = in && (p.mask == nullptr || p.mask[(long)b * p.mask_sb + i] != 0);
-    s_coef[i] = (in && (keep || !key_mask)) ? p.scale * LOG2E : 0.f;
-    s_pen[i] = in ? ((keep || !key_mask) ? 0.f : NEG_MASK * LOG2E) : -INFINITY;
-  }
   const uint8_t* __restrict__ mrow = QMASK ? p.mask + (long)b * p.mask_sb + (long)(q_ok ? q_row : 0) * p.mask_sq : nullptr;
+
+  // ---- K/V staging: direct-to-LDS loads (no staging registers, no ds_write).  Wave w fills tile rows [16w, 16w+16) of
+  // an operand, two rows (1 KiB) per instruction: lane l writes chunk (l & 31) of row 16w + 2i + (l >> 5).  Rows are
+  // XOR-swizzled in LDS -- K: 16-byte chunk ^= row & 15 (the 16 rows of a ds_read_b128 group hit 16 different slots),
+  // V: chunk ^= (row & 3) << 2 (the 4 rows of a transposed-read block hit 4 different bank quarters) -- and the
+  // swizzle is applied on the SOURCE address.
+  constexpr int CPR = DK / 8;                          // 16-byte chunks per row (32 / 16)
+  constexpr int RPI = 64 / CPR;                        // rows per instruction (2 / 4): one wave instruction moves 1 KiB
+  constexpr int GL = BN / (QW * KW) / RPI;             // instructions per wave per operand per tile (8 / 4)
+  const int hi = lane / CPR, pch = lane % CPR;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wrow = wave_s * (BN / (QW * KW));
+  // Addressing: every load of an operand tile uses ONE uniform base (tile row k0 + 16w, in SGPRs) plus a per-lane
+  // 32-bit byte offset that is fixed for the whole launch, and instruction i carries the immediate offset 1024*(i & 3),
+  // which the hardware adds to BOTH the global and the LDS address (so it is subtracted from the lane offset here):
+  // no per-load address arithmetic is left in the loop.
+  unsigned koffb[GL], voffb[GL];
+#pragma unroll
+  for (int i = 0; i < GL; ++i) {
+    const int r = RPI * i + hi;                        // row inside the wave's 16-row group
+    koffb[i] = (unsigned)(r * (int)p.ldk * 2 + ((pch ^ (r & 15)) << 4) - 1024 * (i & 3));
+    voffb[i] = (unsigned)(r * (int)p.ldv * 2 + ((pch ^ ((r & 3) << 2)) << 4) - 1024 * (i & 3));
+  }
+  const char* __restrict__ Kgb = reinterpret_cast<const char*>(Kg);
+  const char* __restrict__ Vgb = reinterpret_cast<const char*>(Vg);
+  // tiles are requested in order (K: 0, 1, 2, ...; V likewise), so each operand keeps a running uniform row pointer
+  const char* k_next = Kgb + (long)wrow * p.ldk * 2;
+  const char* v_next = Vgb + (long)wrow * p.ldv * 2;
+  auto issue_tile = [&](const char* gb, const char*& next, const long ld, const unsigned (&offb)[GL], const int swz_k,
+                        const int t, bf16_t* sdst) {
+    const int k0 = t * BN;
+    const char* base = next;                                       // uniform: row k0 + 16 w of this batch row
+    next += (long)BN * ld * 2;
+    if (k0 + BN <= p.Sk) {
+      static_for<0, GL>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        unsigned o = offb[I];
+        asm volatile("" : "+v"(o));      // keep the 32-bit lane offset as it is: (SGPR base + VGPR offset) addressing
+        glds16<1024 * (I & 3)>(base + o, sdst + (I / 4) * 4 * RPI * DK);
+      });
+    } else {   // ragged last tile: clamp the key row (its score gets pen = -inf, so P is exactly 0 there; V must be finite)
+      static_for<0, GL>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        const int r = RPI * I + hi;
+        const int gr = min(k0 + wrow + r, p.Sk - 1);
+        const int sw = swz_k ? (pch ^ (r & 15)) : (pch ^ ((r & 3) << 2));
+        glds16<0>(gb + (unsigned)(gr * (int)ld * 2 + (sw << 4)), sdst + RPI * I * DK);
+      });
+    }
+  };
+  auto issue_k = [&](int t, int buf) { issue_tile(Kgb, k_next, p.ldk, koffb, 1, t, smem + buf * VST + wrow * DK); };
+  auto issue_v = [&](int t, int buf) { issue_tile(Vgb, v_next, p.ldv, voffb, 0, t, smem + (2 + buf) * VST + wrow * DK); };
+  issue_k(0, 0);          // with Q and the mask bytes: what the first S^T chain needs; V(0) and K(1) follow below
+  BMHRL_STAMP(1)
+  // key-mask bytes of this thread's keys, all requested before the first use (one exposed latency, shared with Q and the
+  // first K/V stages, instead of one per 256 keys)
+  constexpr int NCO = (MAXK + NT - 1) / NT;
+  uint8_t mk[NCO];
+  if constexpr (key_mask) {
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) {
+      const int i = tid + NT * j;
+      mk[j] = (p.mask != nullptr && i < p.Sk) ? p.mask[(long)b * p.mask_sb + i] : (uint8_t)1;
+    }
+  }
 
   // Q^T fragments: lane (q = r32, h) holds Q[q][16*step + 8h .. +8)
   bf16x8 qf[DK / 16];
@@ -158,63 +252,24 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
     for (int s = 0; s < DK / 16; ++s) asm volatile("" : "+a"(qf[s]));
   }
 
-  // ---- K/V staging: direct-to-LDS loads (no staging registers, no ds_write).  Wave w fills tile rows [16w, 16w+16) of
-  // an operand, two rows (1 KiB) per instruction: lane l writes chunk (l & 31) of row 16w + 2i + (l >> 5).  Rows are
-  // XOR-swizzled in LDS -- K: 16-byte chunk ^= row & 15 (the 16 rows of a ds_read_b128 group hit 16 different slots),
-  // V: chunk ^= (row & 3) << 2 (the 4 rows of a transposed-read block hit 4 different bank quarters) -- and the
-  // swizzle is applied on the SOURCE address.
-  constexpr int CPR = DK / 8;                          // 16-byte chunks per row (32 / 16)
-  constexpr int RPI = 64 / CPR;                        // rows per instruction (2 / 4): one wave instruction moves 1 KiB
-  constexpr int GL = BN / (QW * KW) / RPI;             // instructions per wave per operand per tile (8 / 4)
-  const int hi = lane / CPR, pch = lane % CPR;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const int wrow = wave_s * (BN / (QW * KW));
-  int koff[GL], voff[GL];                              // lane part of the source offsets (elements)
+  BMHRL_STAMP(2)
+  // per-key coefficients; the 64 keys a wave handles in pass j are exactly tile 4j + wave, so one ballot per pass tells
+  // which (tile, key half) pairs need the per-key path
 #pragma unroll
-  for (int i = 0; i < GL; ++i) {
-    const int r = RPI * i + hi;                        // row inside the wave's 16-row group
-    koff[i] = hi * (int)p.ldk + ((pch ^ (r & 15)) << 3);
-    voff[i] = hi * (int)p.ldv + ((pch ^ ((r & 3) << 2)) << 3);
+  for (int j = 0; j < NCO; ++j) {
+    const int i = tid + NT * j;
+    const bool in = i < p.Sk;
+    bool keep = in;
+    if constexpr (key_mask) keep = in && mk[j] != 0;
+    const float pen = in ? ((keep || !key_mask) ? 0.f : NEG_MASK * LOG2E) : -INFINITY;
+    if (i < nt * BN) {
+      s_coef[i] = (in && (keep || !key_mask)) ? p.scale * LOG2E : 0.f;
+      s_pen[i] = pen;
+    }
+    const uint64_t bal = __ballot(pen != 0.f);
+    const int tile = (NT / BN) * j + wave_s * 64 / BN;
+    if (lane == 0 && tile < nt) s_slow[tile] = bal;
   }
-  auto glds16 = [](const bf16_t* src, bf16_t* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-  auto issue_k = [&](int t, int buf) {
-    bf16_t* sK = smem + buf * VST + wrow * DK;
-    const int k0 = t * BN;
-    if (k0 + BN <= p.Sk) {
-      const bf16_t* Kt = Kg + (long)(k0 + wrow) * p.ldk;          // uniform
-#pragma unroll
-      for (int i = 0; i < GL; ++i) glds16(Kt + (long)(RPI * i) * p.ldk + koff[i], sK + RPI * i * DK);
-    } else {   // ragged last tile: clamp the key row (its score gets pen = -inf, so P is exactly 0 there)
-#pragma unroll
-      for (int i = 0; i < GL; ++i) {
-        const int r = RPI * i + hi;
-        const long gr = min(k0 + wrow + r, p.Sk - 1);
-        glds16(Kg + gr * p.ldk + ((pch ^ (r & 15)) << 3), sK + RPI * i * DK);
-      }
-    }
-  };
-  auto issue_v = [&](int t, int buf) {
-    bf16_t* sV = smem + (2 + buf) * VST + wrow * DK;
-    const int k0 = t * BN;
-    if (k0 + BN <= p.Sk) {
-      const bf16_t* Vt = Vg + (long)(k0 + wrow) * p.ldv;          // uniform
-#pragma unroll
-      for (int i = 0; i < GL; ++i) glds16(Vt + (long)(RPI * i) * p.ldv + voff[i], sV + RPI * i * DK);
-    } else {   // ragged: the probability is exactly 0 there, but the data must be finite
-#pragma unroll
-      for (int i = 0; i < GL; ++i) {
-        const int r = RPI * i + hi;
-        const long gr = min(k0 + wrow + r, p.Sk - 1);
-        glds16(Vg + gr * p.ldv + ((pch ^ ((r & 3) << 2)) << 3), sV + RPI * i * DK);
-      }
-    }
-  };
-  issue_k(0, 0);
-  issue_v(0, 0);
-  if (nt > 1) issue_k(1, 1);
 
   f32x16 o[DK / 32];
 #pragma unroll
@@ -257,11 +312,18 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   };
   // lazy rescale (only when some row's max grew by more than RESCALE_THR): everything accumulated so far is at the old
   // max and P of the new tile has not been exponentiated yet, so O and l are scaled exactly once
-  auto maybe_rescale = [&](const float m_tile, const bool have_o) {
+  // `fix_args`: the exponential arguments in `sc` were already formed with the old max (the common case needs no second
+  // pass over the scores); shift them to the new one.
+  auto maybe_rescale = [&](const float m_tile, const bool have_o, const bool fix_args, f32x16& args) {
     if (__any(m_tile > m_run + RESCALE_THR)) {
       const float m_new = fmaxf(m_run, m_tile);
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
+      if (fix_args) {
+        const float shift = ((m_run == -INFINITY) ? 0.f : m_run) - ((m_new == -INFINITY) ? 0.f : m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) args[r] += shift;
+      }
       if (have_o) {
         // O^T lives in the accumulator file (MFMA C/D).  The rescale is rare; each d-tile is handed to the asm as ONE
         // 16-register operand bound to a fixed accumulator range, so the compiler neither splits the tuples nor copies
@@ -299,15 +361,33 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   };
   // tiles whose 32 keys (of this wave) are all valid and unmasked -- nearly all of them -- only need score * c
   const float c_log2 = p.scale * LOG2E;
-  auto scale_scores_fast = [&](const f32x16& raw, f32x16& sc) {
-    float m_tile = -INFINITY;
+  // Fast tiles: max over the raw scores (the scale is positive), then  x = raw * c - max  as ONE packed fma per two scores;
+  // `sc` always holds the exponential ARGUMENTS of the tile in flight (log2 domain, max already subtracted).
+  auto raw_max = [&](const f32x16& raw) {
+    float m = raw[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sc[r] = raw[r] * c_log2;
-      m_tile = fmaxf(m_tile, sc[r]);
-    }
-    return pair_max(m_tile);
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, raw[r]);
+    return pair_max(m) * c_log2;
   };
+  auto args_fast = [&](const f32x16& raw, f32x16& sc, const float m_use) {
+    const f32x2 c2 = {c_log2, c_log2}, nm2 = {-m_use, -m_use};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 v = f32x2{raw[r], raw[r + 1]} * c2 + nm2;
+      sc[r] = v[0];
+      sc[r + 1] = v[1];
+    }
+  };
+  auto args_slow = [&](f32x16& sc, const float m_use) {      // sc holds scaled + masked scores
+    const f32x2 nm2 = {-m_use, -m_use};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 v = f32x2{sc[r], sc[r + 1]} + nm2;
+      sc[r] = v[0];
+      sc[r + 1] = v[1];
+    }
+  };
+  auto max_for_exp = [&]() { return (m_run == -INFINITY) ? 0.f : m_run; };
 
   // ---- S^T chain of one tile: K fragments by ds_read_b128 (asm), first half of the chain starts as soon as the first 8
   // fragments are there; `mid` runs between the two halves (it issues the V^T reads of the tile in flight), `step(st)`
@@ -322,7 +402,7 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
       for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(kf[8 + st]) : "v"(k_addr[st] + koffs));
     }
   };
-  // `step(e)` is called 16 times over the chain (one exponential of the previous tile per call)
+  // `step(i)`, i = 0..7, is called at even spacing over the chain (two exponentials of the previous tile per call)
   auto qk_chain = [&](auto&& mid, auto&& step) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
@@ -331,7 +411,7 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
-        step(st);
+        if (st & 1) step(st >> 1);
       }
       mid();
       // in-order returns: at most 15 younger reads outstanding means the 16 K fragments are all there
@@ -339,46 +419,55 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
 #pragma unroll
       for (int st = 8; st < 16; ++st) {
         s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
-        step(st);
+        if (st & 1) step(st >> 1);
       }
     } else {
       asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
-        step(2 * st);
-        step(2 * st + 1);
+        step(st);
       }
       mid();                                   // 16 V^T reads: younger than every K fragment
       asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
 #pragma unroll
       for (int st = 4; st < 8; ++st) {
         s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s_acc, 0, 0, 0);
-        step(2 * st);
-        step(2 * st + 1);
+        step(st);
       }
     }
   };
 
-  __syncthreads();   // coefficients written; also drains the first K/V stages (direct-to-LDS loads count on vmcnt)
+  BMHRL_STAMP(3)
+  // K(0) has landed (the wait in front of the first use of Q / the mask bytes drained every load); V(0) and K(1) now go
+  // out and land under the first S^T chain, so the barrier here must not wait for them: LDS counter only
+  issue_v(0, 0);
+  if (nt > 1) issue_k(1, 1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // coefficient / ballot writes
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  BMHRL_STAMP(4)
   qk_issue(0u);
   qk_chain([] {}, [](int) {});
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();      // every wave is done with K stage 0: the loop refills it right away
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();      // V(0), K(1) are there, and every wave is done with K stage 0 (the loop refills it)
   asm volatile("" ::: "memory");
+  BMHRL_STAMP(5)
   uint64_t slow_bits = 0;            // bit t: tile t has a masked or padding key among this wave's 32 (wave-uniform)
   if constexpr (QMASK) {
     slow_bits = ~0ull;
   } else {
-    for (int t = 0; t < nt; ++t)
-      if (__any(s_pen[t * BN + 32 * ki + r32] != 0.f)) slow_bits |= 1ull << t;
+    static_assert(BN == 64 && MAXT <= 64, "one ballot word per tile, one lane per tile");
+    const uint64_t w = lane < nt ? s_slow[lane] : 0ull;
+    slow_bits = __ballot((unsigned)(w >> (32 * ki)) != 0u);
   }
   {
     f32x4 cf[4], pn[4];
     read_coef(c_addr, cf, pn);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pn[3]));
     const float m_tile = scale_scores(s_acc, sc, 0, cf, pn);
-    maybe_rescale(m_tile, false);
+    maybe_rescale(m_tile, false, false, sc);
+    args_slow(sc, max_for_exp());
   }
 
   // ---- main loop.  Iteration t:  phase 1  P(t) = exp2(scores(t) - max)  ||  S^T(t+1) = K(t+1) . Q^T (K fragments are
@@ -405,6 +494,12 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
       for (int ks = 0; ks < 2; ++ks)
         o[d0 + dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd][ks], pf[ks], o[d0 + dd], 0, 0, 0);
   };
+  auto tile_sum = [](const f32x16& e) {      // packed adds, as a tree (no dependent chain)
+    const f32x2 a = f32x2{e[0], e[1]} + f32x2{e[2], e[3]}, b = f32x2{e[4], e[5]} + f32x2{e[6], e[7]};
+    const f32x2 c = f32x2{e[8], e[9]} + f32x2{e[10], e[11]}, d = f32x2{e[12], e[13]} + f32x2{e[14], e[15]};
+    const f32x2 r = (a + b) + (c + d);
+    return r[0] + r[1];
+  };
   auto pack_p = [&]() {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -415,42 +510,48 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
 
+  BMHRL_STAMP(6)
   for (int t = 0; t + 1 < nt; ++t) {
     const int cur = t & 1;                     // V stage of tile t == K stage of tile t+2; K(t+1), V(t+1) use stage cur^1
+    qk_issue((unsigned)(cur ^ 1) * (VST * 2)); // K(t+1) fragments: their LDS latency passes under the load issue below
     if (p.dbg != 1) {                          // (tuning aid: dbg 1 times the loop without its loads)
       if (t + 2 < nt) issue_k(t + 2, cur);     // K(t) was read in the previous iteration, V(t-1) too
       issue_v(t + 1, cur ^ 1);
     }
     const unsigned soff = (unsigned)cur * (VST * 2);
     {
-      const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-      float psum = 0.f;
-      qk_issue((unsigned)(cur ^ 1) * (VST * 2));
       qk_chain([&] { read_vt(soff, H0{}); },     // V^T(t), d-tiles 0..3: wanted at the start of phase 2
-               [&](const int st) {               // one exponential of tile t under every MFMA of tile t+1
-                 const float e = __builtin_amdgcn_exp2f(sc[st] - m_use);
-                 sc[st] = e;
-                 psum += e;
+               [&](const int i) {                // two exponentials of tile t at a time under the MFMAs of tile t+1
+                 sc[2 * i] = __builtin_amdgcn_exp2f(sc[2 * i]);
+                 sc[2 * i + 1] = __builtin_amdgcn_exp2f(sc[2 * i + 1]);
                });
-      l_run += psum;
+      l_run += tile_sum(sc);
       pack_p();
     }
     wait_vt();
     pv(0);
     if constexpr (DK == 256) read_vt(soff, H1{});
     c_addr += BN * 4;
-    float m_tile = scale_scores_fast(s_acc, sc);   // independent of the MFMAs around it: the VALU work hides under them
+    // phase 2 VALU work (independent of the MFMAs around it, hides under them): row max of tile t+1, the rare rescale,
+    // and the exponential arguments of tile t+1
+    const bool slow = (slow_bits >> (t + 1)) & 1;    // wave-uniform, rare: per-key coefficients (masked / padding keys)
+    float m_tile;
+    if (!slow) {
+      m_tile = raw_max(s_acc);
+      args_fast(s_acc, sc, max_for_exp());           // with the max as it stands: nearly always the final one
+    }
     if constexpr (DK == 256) {
       wait_vt();
       pv(4);
     }
-    if ((slow_bits >> (t + 1)) & 1) {              // wave-uniform, rare: redo the scores with the per-key coefficients
+    if (slow) {
       f32x4 cf[4], pn[4];
       read_coef(c_addr, cf, pn);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cf[0]), "+v"(cf[1]), "+v"(cf[2]), "+v"(cf[3]), "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pn[3]));
       m_tile = scale_scores(s_acc, sc, (t + 1) * BN, cf, pn);
+      args_slow(sc, max_for_exp());
     }
-    maybe_rescale(m_tile, true);
+    maybe_rescale(m_tile, true, true, sc);
 
     // ---- the loads issued at the top of this iteration (K tile t+2, V tile t+1) have had the whole iteration to land;
     // the barrier publishes them and retires K stage cur^1 / V stage cur for the next refill
@@ -458,18 +559,13 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  BMHRL_STAMP(7)
   {   // last tile: exponentials and O^T only
     const unsigned soff = (unsigned)((nt - 1) & 1) * (VST * 2);
     read_vt(soff, H0{});
-    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-    float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(sc[r] - m_use);
-      sc[r] = e;
-      psum += e;
-    }
-    l_run += psum;
+    for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+    l_run += tile_sum(sc);
     pack_p();
     wait_vt();
     pv(0);
@@ -483,66 +579,107 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
     asm volatile("" ::: "memory");
   }
 
-  // ---- merge the KW partial states of each query block (ki > 0 publish through LDS, ki == 0 combines)
-  if (KW > 1) {
-    float* mg = reinterpret_cast<float*>(smem_raw);
-    // layout: [(ki-1)*QW + qi][130 rows][64 lanes] ; rows 0..OREGS-1 = o regs, then m, then l
-    if (ki > 0) {
-      float* dst = mg + ((ki - 1) * QW + qi) * (OREGS + 2) * 64 + lane;
-#pragma unroll
-      for (int d = 0; d < DK / 32; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = o[d][r];
-      dst[OREGS * 64] = m_run;
-      dst[(OREGS + 1) * 64] = l_run;
-    }
-    __syncthreads();
-    if (ki == 0) {
-#pragma unroll
-      for (int k2 = 1; k2 < KW; ++k2) {
-        const float* src = mg + ((k2 - 1) * QW + qi) * (OREGS + 2) * 64 + lane;
-        const float m2 = src[OREGS * 64], l2 = src[(OREGS + 1) * 64];
-        const float m = fmaxf(m_run, m2);
-        const float ms = (m == -INFINITY) ? 0.f : m;
-        const float a1 = __builtin_amdgcn_exp2f(m_run - ms), a2 = __builtin_amdgcn_exp2f(m2 - ms);
-#pragma unroll
-        for (int d = 0; d < DK / 32; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a1 + src[(d * 16 + r) * 64] * a2;
-        l_run = l_run * a1 + l2 * a2;
-        m_run = m;
-      }
-    }
-  }
-
+  BMHRL_STAMP(8)
+  // ---- merge + output.  The two waves of a query block hold partial states (O^T over all DK columns, row max, row sum)
+  // for disjoint keys.  Each keeps HALF of the columns (wave ki: d-tiles [ki*NH, ki*NH+NH)) and sends the other half to
+  // its partner through LDS, so both waves share the combine, the normalisation and the stores; the finished bf16 rows
+  // go through a padded LDS image so that every store instruction writes whole 16-byte pieces of contiguous rows
+  // (the O^T register layout holds one query row per lane: stored directly, one instruction touches 64 cache lines).
+  static_assert(KW == 2, "pairwise exchange");
+  constexpr int ND = DK / 32, NH = ND / 2;
+  constexpr int XSLOTS = NH * 4 + 1;                       // float4 slots per lane: NH*16 accumulators + (m, l)
+  constexpr int ROWB = NH * 64 + 16;                       // bytes per row of the output image (padded)
+  constexpr int XCH_BYTES = QW * KW * XSLOTS * 64 * 16;
+  static_assert(XCH_BYTES + QW * KW * 32 * ROWB <= LDS_KV, "exchange + output images reuse the K/V stages");
   l_run += __shfl_xor(l_run, 32, 64);   // the two 32-lane halves hold disjoint keys of the same query row
-  if (ki == 0 && q_ok) {
-    const float inv = 1.0f / l_run;
-    if (h == 0) {
-      const long si = ((long)b * p.H + hd) * p.Sq + q_row;
-      // statistics in natural-log units: P = exp(score - row_max) / row_sum.  A fully masked row keeps the exact
-      // fill value so that the backward recomputation exp(-1e9 - row_max) is exp(0).
-      p.row_max[si] = (m_run <= NEG_MASK * LOG2E) ? NEG_MASK : m_run * LN2;
-      p.row_sum[si] = l_run;
-    }
-    bf16_t* op = p.O + ((long)b * p.Sq + q_row) * p.ldo + hd * DK + 4 * h;
-    const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
-    const uint64_t ebase = ((uint64_t)b * p.Sq + q_row) * (uint64_t)(p.H * DK) + hd * DK + 4 * h;
+  f32x4* xch = reinterpret_cast<f32x4*>(smem_raw);
+  f32x4* mine = xch + (qi * KW + ki) * XSLOTS * 64 + lane;
+  const f32x4* theirs = xch + (qi * KW + (ki ^ 1)) * XSLOTS * 64 + lane;
+  char* img = smem_raw + XCH_BYTES + (qi * KW + ki) * 32 * ROWB;
+  const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
+  float m_all = 0.f, l_all = 0.f;
+  auto send = [&](auto keep) {
+    constexpr int SEND = (decltype(keep)::value ^ 1) * NH;
 #pragma unroll
-    for (int d = 0; d < DK / 32; ++d) {
+    for (int dd = 0; dd < NH; ++dd)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = o[SEND + dd][4 * g + j];
+        mine[(dd * 4 + g) * 64] = v;
+      }
+    {
+      f32x4 v;
+      v[0] = m_run; v[1] = l_run; v[2] = 0.f; v[3] = 0.f;
+      mine[NH * 4 * 64] = v;
+    }
+  };
+  auto finish = [&](auto keep, auto drop) {
+    constexpr int MY = decltype(keep)::value * NH;
+    constexpr bool DROP = decltype(drop)::value;
+    const f32x4 st = theirs[NH * 4 * 64];
+    const float m = fmaxf(m_run, st[0]);
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    float a1 = __builtin_amdgcn_exp2f(m_run - ms), a2 = __builtin_amdgcn_exp2f(st[0] - ms);
+    m_all = m;
+    l_all = l_run * a1 + st[1] * a2;
+    const float inv = __builtin_amdgcn_rcpf(l_all);      // 1 ulp; the output is rounded to bf16
+    a1 *= inv;
+    a2 *= inv;
+    const uint64_t ebase = ((uint64_t)b * p.Sq + q_row) * (uint64_t)(p.H * DK) + hd * DK + 4 * h;
+    f32x4 got[NH * 4];                                     // all reads first: one LDS latency, not one per slot
+#pragma unroll
+    for (int sl = 0; sl < NH * 4; ++sl) got[sl] = theirs[sl * 64];
+#pragma unroll
+    for (int dd = 0; dd < NH; ++dd)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = o[d][4 * g + j] * inv;
-          if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seed, ebase + 32 * d + 8 * g + j);
-          w[j] = (bf16_t)v;
+          float x = o[MY + dd][4 * g + j] * a1 + got[dd * 4 + g][j] * a2;
+          if constexpr (DROP) x *= dropout_scale(p.dropout_p, seed, ebase + 32 * (MY + dd) + 8 * g + j);
+          w[j] = (bf16_t)x;
         }
-        *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * g) = w;
+        *reinterpret_cast<bf16x4*>(img + r32 * ROWB + (dd * 32 + 8 * g + 4 * h) * 2) = w;
       }
+    // rows of the image -> global: CPRO 16-byte pieces per row, 64 / CPRO rows per instruction
+    constexpr int CPRO = NH * 4, RPS = 64 / CPRO, NST = 32 / RPS;
+    const int srow = lane / CPRO, sch = lane % CPRO;
+    const int q0 = qt * (32 * QW) + qi * 32;
+    bf16x8 wout[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) wout[i] = *reinterpret_cast<const bf16x8*>(img + (RPS * i + srow) * ROWB + sch * 16);
+    bf16_t* op = p.O + ((long)b * p.Sq + q0 + srow) * p.ldo + hd * DK + MY * 32 + sch * 8;
+    const long ostep = (long)RPS * p.ldo;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      if (q0 + RPS * i + srow < p.Sq) *reinterpret_cast<bf16x8*>(op) = wout[i];
+      op += ostep;
     }
+  };
+  BMHRL_STAMP(9)
+  if (ki == 0) send(std::integral_constant<int, 0>{});
+  else send(std::integral_constant<int, 1>{});
+  __syncthreads();
+  using DropOff = std::integral_constant<bool, false>;
+  using DropOn = std::integral_constant<bool, true>;
+  if (p.dropout_p > 0.f) {
+    if (ki == 0) finish(std::integral_constant<int, 0>{}, DropOn{});
+    else finish(std::integral_constant<int, 1>{}, DropOn{});
+  } else {
+    if (ki == 0) finish(std::integral_constant<int, 0>{}, DropOff{});
+    else finish(std::integral_constant<int, 1>{}, DropOff{});
   }
+  if (ki == 0 && h == 0 && q_ok) {
+    const long si = ((long)b * p.H + hd) * p.Sq + q_row;
+    // statistics in natural-log units: P = exp(score - row_max) / row_sum.  A fully masked row keeps the exact
+    // fill value so that the backward recomputation exp(-1e9 - row_max) is exp(0).
+    p.row_max[si] = (m_all <= NEG_MASK * LOG2E) ? NEG_MASK : m_all * LN2;
+    p.row_sum[si] = l_all;
+  }
+  BMHRL_STAMP(10)
 }
 
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, long lddo, const bf16_t* __restrict__ O, long ldo,
@@ -599,9 +736,9 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
   BMHRL_CHECK_ARG(Q && K && V && O && row_max && row_sum);
   BMHRL_CHECK_ARG(dk == DK);  // d_model 1024 / H 4 of the reference; other head sizes use the materialised path
   BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 2048);
-  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
+  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
   BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldk >= (int64_t)H * DK && ldv >= (int64_t)H * DK && ldo >= (int64_t)H * DK);
-  BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && ((uintptr_t)O & 7) == 0);
+  BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0);
   BMHRL_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
   AttnArgs a;
   a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
@@ -611,6 +748,8 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
   a.k_hs = DK; a.v_hs = DK;
   a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
   a.dbg = getenv("BMHRL_ATTN_DBG") ? atoi(getenv("BMHRL_ATTN_DBG")) : 0;
+  BMHRL_CHECK_ARG((int64_t)B * H * a.q_tiles * H * a.q_tiles < (1ll << 32));
+  set_block_map(a);
   dim3 grid((unsigned)(B * H * a.q_tiles)), block(NT);
   if (mask != nullptr && mask_sq != 0) hipLaunchKernelGGL((attn_fwd_kernel<DK, true>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<DK, false>), grid, block, 0, (hipStream_t)stream, a);
@@ -624,9 +763,9 @@ extern "C" int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const 
   constexpr int DK = 128;
   BMHRL_CHECK_ARG(Qp && X && ctx && row_max && row_sum);
   BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 1024);
-  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldx % 8 == 0 && ldo % 4 == 0);
+  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0);
   BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldx >= DK && ldo >= (int64_t)H * DK);
-  BMHRL_CHECK_ARG((((uintptr_t)Qp | (uintptr_t)X) & 15) == 0 && ((uintptr_t)ctx & 7) == 0);
+  BMHRL_CHECK_ARG((((uintptr_t)Qp | (uintptr_t)X | (uintptr_t)ctx) & 15) == 0);
   AttnArgs a;
   a.Q = (const bf16_t*)Qp; a.ldq = ldq; a.K = (const bf16_t*)X; a.ldk = ldx; a.V = (const bf16_t*)X; a.ldv = ldx;
   a.O = (bf16_t*)ctx; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
@@ -635,8 +774,22 @@ extern "C" int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const 
   a.k_hs = 0; a.v_hs = 0;                       // one 128-wide key / value row for every head
   a.q_tiles = (Sq + 32 * QW - 1) / (32 * QW);
   a.dbg = 0;
+  BMHRL_CHECK_ARG((int64_t)B * H * a.q_tiles * H * a.q_tiles < (1ll << 32));
+  set_block_map(a);
   dim3 grid((unsigned)(B * H * a.q_tiles)), block(NT);
   hipLaunchKernelGGL((attn_fwd_kernel<DK, false>), grid, block, 0, (hipStream_t)stream, a);
+#ifdef BMHRL_ATTN_TRACE
+  if (getenv("BMHRL_ATTN_TRACE")) {
+    long long h[2][16];
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_trace), sizeof(h));
+    for (int w = 0; w < 2; ++w) {
+      fprintf(stderr, "attn128 trace (%s block, Sq %d Sk %d):", w ? "last" : "first", Sq, Sk);
+      for (int i = 1; i <= 10; ++i) fprintf(stderr, " %lld", h[w][i] - h[w][i - 1]);
+      fprintf(stderr, "  total %lld\n", h[w][10] - h[w][0]);
+    }
+  }
+#endif
   return hip_status(hipGetLastError());
 }
 

@@ -72,8 +72,8 @@ int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
  * Replaces attention() + the head split/merge views, model/multihead_attention.py:7-31,75-86:
  *   O[b,q,h,:] = softmax_k( Q[b,q,h,:].K[b,k,h,:] * scale ; mask==0 -> -1e9 ) . V[b,k,h,:]
  * Q,K,V,O are bf16 (B, S, H*DK) row-major with leading dims ldq/ldk/ldv/ldo (heads are column
- * slices, exactly the .view(B,-1,H,d_k) of the reference).  DK must be 256 (the reference's
- * d_model 1024 / H 4).  mask: bytes, mask[b*mask_sb + q*mask_sq + k], mask_sq = 0 for key-padding
+ * slices, exactly the .view(B,-1,H,d_k) of the reference; base pointers 16-byte aligned, leading
+ * dims multiples of 8 elements).  DK must be 256 (the reference's d_model 1024 / H 4).  mask: bytes, mask[b*mask_sb + q*mask_sq + k], mask_sq = 0 for key-padding
  * masks (B,1,Sk).  row_max / row_sum (B,H,Sq) fp32 = softmax statistics of the masked scaled scores, kept
  * separately (not as one log-sum-exp) so that fully masked rows (all scores -1e9) stay exact in backward.
  * dropout_p > 0 applies the reference's dropout on the attention OUTPUT (:27-28).

@@ -25,26 +25,28 @@ def _regs(text):
 
 
 def _early_uses(lines):
-    pending, bad = {}, []
+    """Every LDS instruction (reads AND writes) and scalar memory read counts on lgkmcnt; LDS operations return in order."""
+    ops, bad = [], []            # ops: outstanding lgkm operations, oldest first: (is_smem, registers it will write)
     for i, l in enumerate(lines):
         s = l.strip()
         if not s or s.startswith(";") or s.endswith(":"):
             continue
         op = s.split()[0]
-        if op.startswith("ds_read"):
-            for r in _regs(s.split()[1].rstrip(",")):
-                pending[r] = i
+        if op.startswith("ds_"):
+            dst = _regs(s.split()[1].rstrip(",")) if op.startswith("ds_read") or "_rtn" in op or "permute" in op else set()
+            ops.append((False, dst))
+        elif op.startswith("s_load") or op.startswith("s_memtime") or op.startswith("s_buffer_load"):
+            ops.append((True, set()))
         elif op == "s_waitcnt" and "lgkmcnt" in s:
             n = int(re.search(r"lgkmcnt\((\d+)\)", s).group(1))
             if n == 0:
-                pending.clear()
-            else:        # reads return in order: the newest n may still be outstanding
-                order = sorted(set(pending.values()))
-                keep = set(order[-n:])
-                pending = {r: v for r, v in pending.items() if v in keep}
-        elif op in ("s_barrier", "s_endpgm"):
-            pending.clear()
+                ops = []
+            elif not any(sm for sm, _ in ops):        # scalar reads return out of order: only lgkmcnt(0) covers them
+                ops = ops[len(ops) - n:] if n < len(ops) else ops
+        elif op == "s_endpgm":
+            ops = []
         else:
+            pending = set().union(*[d for _, d in ops]) if ops else set()
             hit = sorted(r for r in _regs(" ".join(s.split()[1:])) if r in pending)
             if hit:
                 bad.append((i, s, hit[:4]))
