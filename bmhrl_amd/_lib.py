@@ -43,6 +43,7 @@ PROTOTYPES = {
     "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_layernorm_bwd_ws": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr, i64, ptr],
     "bmhrl_add_posenc": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, f32, u64, ptr, ptr],
     "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
@@ -91,6 +92,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.bmhrl_layernorm_bwd_workspace.argtypes = [i64, i32]
+    lib.bmhrl_layernorm_bwd_workspace.restype = C.c_int64
     lib.bmhrl_hip_arch.restype = C.c_char_p
     lib.bmhrl_hip_abi_version.restype = C.c_int
     _lib = lib

@@ -159,45 +159,55 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
 
 // Same, D % 4 == 0: every lane owns NV groups of 4 consecutive columns (16-byte loads / stores, gamma hoisted out of
 // the row loop) -- 4x fewer memory instructions per row than the column-strided kernel above.
-template <int NV>
-__global__ void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+// PART: instead of the atomics, every block stores its column sums to part[block][0..D) (dgamma) and [D..2D) (dbeta);
+// ln_bwd_reduce_kernel adds them up.  All blocks adding into the same 2*D addresses is the slow case of the float
+// atomics (serialised at the memory side: 256 blocks x 2048 columns cost ~23 us), and it is what kept the block count
+// (hence the rows in flight) low.
+template <int NV, bool PART>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                   const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
                                   const float* __restrict__ dx_add, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                  long rows, int D, int rows_per_wave) {
+                                  long rows, int D, int rows_per_wave, float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   const long r0 = wave_id * rows_per_wave;
-  f32x4 dg[NV], db[NV], xv[NV], gv[NV], gam[NV];
+  f32x4 dg[NV], db[NV], gam[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = 4 * lane + 256 * i;
     dg[i] = db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     gam[i] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (long row = r0; row < r0 + rows_per_wave && row < rows; ++row) {
-    const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + row * D;
-    const float* dyr = dy + row * D;
-    float s1 = 0.f, s2 = 0.f;
+  // rows go two at a time: the loads of both are requested before either is reduced, so a wave keeps twice the bytes
+  // in flight (the kernel runs at a few waves per SIMD and every row is a dependent load -> reduce -> store chain)
+  struct Row { f32x4 d[NV], x[NV], a[NV]; float mu, rs; };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_row = [&](const long row, Row& R) {
+    R.mu = mean[row];
+    R.rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = 4 * lane + 256 * i;
-      xv[i] = gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < D) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dyr + c);
-        const f32x4 xx = *reinterpret_cast<const f32x4*>(xr + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float xh = (xx[j] - mu) * rs, g = d[j] * gam[i][j];
-          xv[i][j] = xh;
-          gv[i][j] = g;
-          s1 += g;
-          s2 += g * xh;
-          dg[i][j] += d[j] * xh;
-          db[i][j] += d[j];
-        }
-      }
+      const bool in = c < D;
+      R.d[i] = in ? *reinterpret_cast<const f32x4*>(dy + row * D + c) : zero4;
+      R.x[i] = in ? *reinterpret_cast<const f32x4*>(x + row * D + c) : zero4;
+      R.a[i] = (in && dx_add) ? *reinterpret_cast<const f32x4*>(dx_add + row * D + c) : zero4;
     }
+  };
+  auto finish_row = [&](const long row, Row& R) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (R.x[i][j] - R.mu) * R.rs, g = R.d[i][j] * gam[i][j];   // columns >= D: d = 0, gamma = 0
+        s1 += g;
+        s2 += g * xh;
+        dg[i][j] += R.d[i][j] * xh;
+        db[i][j] += R.d[i][j];
+        R.x[i][j] = xh;
+        R.d[i][j] = g;
+      }
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
 #pragma unroll
@@ -206,11 +216,24 @@ __global__ void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __r
       if (c < D) {
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rs * (gv[i][j] - s1 - xv[i][j] * s2);
-        if (dx_add) v += *reinterpret_cast<const f32x4*>(dx_add + row * D + c);
+        for (int j = 0; j < 4; ++j) v[j] = R.rs * (R.d[i][j] - s1 - R.x[i][j] * s2) + R.a[i][j];
         *reinterpret_cast<f32x4*>(dx + row * D + c) = v;
       }
     }
+  };
+  const long rend = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
+  long row = r0;
+  for (; row + 1 < rend; row += 2) {
+    Row A, B;
+    load_row(row, A);
+    load_row(row + 1, B);
+    finish_row(row, A);
+    finish_row(row + 1, B);
+  }
+  if (row < rend) {
+    Row A;
+    load_row(row, A);
+    finish_row(row, A);
   }
   __shared__ float red[ROWS_PER_BLOCK][256 * NV];
   const int w = threadIdx.x >> 6;
@@ -225,8 +248,30 @@ __global__ void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __r
       if (c < D) *reinterpret_cast<f32x4*>(&red[w][c]) = pass == 0 ? dg[i] : db[i];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += blockDim.x)
-      atomicAdd(out + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+      const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      if constexpr (PART) part[((long)blockIdx.x * 2 + pass) * D + c] = v;
+      else atomicAdd(out + c, v);
+    }
+  }
+}
+
+// part (nblk, 2*D) -> dgamma / dbeta += column sums.  Block (cg, rg): 64 columns x every RG-th... the partial rows
+// rg, rg + RG, ...; wave w of the block takes every 4th of those.  One atomic per column per block (RG per column).
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;              // column of the (2*D)-wide partial rows
+  float acc = 0.f;
+  if (c < 2 * D)
+    for (int r = blockIdx.y * 4 + w; r < nblk; r += gridDim.y * 4) acc += part[(long)r * 2 * D + c];
+  __shared__ float red[4][64];
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < 2 * D) {
+    const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float* out = c < D ? dgamma : dbeta;
+    if (out) atomicAdd(out + (c < D ? c : c - D), v);
   }
 }
 
@@ -544,8 +589,8 @@ extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float*
     const long wv = (rows + rv - 1) / rv;
     dim3 gridv((unsigned)((wv + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
     const int nv = (D + 255) / 256;
-#define LN_BWDV(NV_) hipLaunchKernelGGL(ln_bwd_vec_kernel<NV_>, gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
-                                        dx_add, dgamma, dbeta, (long)rows, D, rv)
+#define LN_BWDV(NV_) hipLaunchKernelGGL((ln_bwd_vec_kernel<NV_, false>), gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
+                                        dx_add, dgamma, dbeta, (long)rows, D, rv, (float*)nullptr)
     if (nv <= 1) LN_BWDV(1); else if (nv <= 2) LN_BWDV(2); else LN_BWDV(4);
 #undef LN_BWDV
     return hip_status(hipGetLastError());
@@ -555,6 +600,57 @@ extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float*
                                        dgamma, dbeta, (long)rows, D, rpw)
   if (nc <= 1) LN_BWD(1); else if (nc <= 2) LN_BWD(2); else if (nc <= 5) LN_BWD(5); else if (nc <= 8) LN_BWD(8); else LN_BWD(16);
 #undef LN_BWD
+  return hip_status(hipGetLastError());
+}
+
+// Two-stage variant: ~4 waves per SIMD stream the rows, column sums go through `workspace`.
+static void ln_bwd_ws_plan(int64_t rows, int D, int* rows_per_wave, long* blocks) {
+  // waves: wide rows want few blocks (each ends with a 2*D-float reduction + store), narrow rows many rows in flight;
+  // measured r01 (tests/bench_ln_bwd.py): 4096 x 1024 best at 1024 waves (16.8 us), 12800 x 128 at 4096 (10.6 us)
+  static const int forced = getenv("BMHRL_LN_WS_WAVES") ? atoi(getenv("BMHRL_LN_WS_WAVES")) : 0;
+  int target = forced > 0 ? forced : (1 << 20) / D;
+  if (forced <= 0) target = target < 1024 ? 1024 : (target > 4096 ? 4096 : target);
+  int rv = (int)((rows + target - 1) / target);
+  if (rv < 1) rv = 1;
+  if (rv > 32) rv = 32;
+  const long wv = (rows + rv - 1) / rv;
+  *rows_per_wave = rv;
+  *blocks = (wv + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+}
+
+extern "C" int64_t bmhrl_layernorm_bwd_workspace(int64_t rows, int32_t D) {
+  if (rows <= 0 || D <= 0) return 0;
+  int rv; long blocks;
+  ln_bwd_ws_plan(rows, D, &rv, &blocks);
+  return blocks * 2 * (int64_t)D;
+}
+
+extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                                      int64_t rows, int32_t D, float* workspace, int64_t workspace_floats,
+                                      bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 64 * LN_MAXC);
+  const bool vec = D % 4 == 0 && D <= 1024 &&
+                   ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0);
+  if (!vec || !workspace || (!dgamma && !dbeta) || workspace_floats < bmhrl_layernorm_bwd_workspace(rows, D))
+    return bmhrl_layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D, stream);
+  int rv; long blocks;
+  ln_bwd_ws_plan(rows, D, &rv, &blocks);
+  dim3 gridv((unsigned)blocks), block(256);
+  // a null dgamma / dbeta only skips the final add: the partial kernel fills both halves of the workspace rows it owns
+  float* dg = dgamma ? dgamma : dbeta;
+  float* db = dbeta ? dbeta : dgamma;
+  const int nv = (D + 255) / 256;
+#define LN_BWDP(NV_) hipLaunchKernelGGL((ln_bwd_vec_kernel<NV_, true>), gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
+                                        dx_add, dg, db, (long)rows, D, rv, workspace)
+  if (nv <= 1) LN_BWDP(1); else if (nv <= 2) LN_BWDP(2); else LN_BWDP(4);
+#undef LN_BWDP
+  const int cg = (2 * D + 63) / 64;
+  int rg = (int)((256 + cg - 1) / cg);                         // ~256 blocks in total
+  const int max_rg = (int)((blocks + 3) / 4);
+  if (rg > max_rg) rg = max_rg;
+  if (rg < 1) rg = 1;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cg, rg), block, 0, S_(stream), workspace, (int)blocks, D, dgamma, dbeta);
   return hip_status(hipGetLastError());
 }
 

@@ -100,10 +100,18 @@ def layernorm_fwd(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows, D):
                                                _p(mean), _p(rstd), rows, D, stream()), "bmhrl_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D):
-    _lib.check(_lib.load().bmhrl_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                               dx.data_ptr(), _p(dx_add), _p(dgamma), _p(dbeta), rows, D, stream()),
-               "bmhrl_layernorm_bwd")
+def layernorm_bwd_workspace(rows, D) -> int:
+    """fp32 elements of the scratch the two-stage column sums of layernorm_bwd go through (uninitialised is fine)."""
+    return int(_lib.load().bmhrl_layernorm_bwd_workspace(rows, D))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D, workspace=None):
+    if workspace is None:
+        workspace = torch.empty(layernorm_bwd_workspace(rows, D), device=x.device)
+    _lib.check(_lib.load().bmhrl_layernorm_bwd_ws(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                  dx.data_ptr(), _p(dx_add), _p(dgamma), _p(dbeta), rows, D,
+                                                  workspace.data_ptr(), workspace.numel(), stream()),
+               "bmhrl_layernorm_bwd_ws")
 
 
 def add_posenc(a, b, pe, out, out_bf16, ldob, B, S, D, dropout_p=0.0, seed=0, seed_dev=None):

@@ -226,9 +226,16 @@ class CaptionTrainer:
                                               # copy, not allowed while capturing); the captured body reuses it
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        alone = self._world_scale() == 1.0 and not self._split()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self._graph_body_a()
+            if alone:                         # no all-reduce to leave room for: the optimizer joins the same graph
+                self._graph_body_b(1.0)
+        if alone:
+            self.graph_b = None
+            self.graph = True
+            return
         if self._split():
             self.graph_a2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool()):
@@ -292,6 +299,8 @@ class CaptionTrainer:
                 self.static[k].copy_(fs[k])
             self.static["captions"].copy_(captions)
         self.graph_a.replay()
+        if self.graph_b is None:                  # single process: forward, backward and Adam are one graph
+            return self.static_loss
         if self._split():
             w0 = self.opt.all_reduce_part(0)      # overlaps the encoder backward below
             self.graph_a2.replay()

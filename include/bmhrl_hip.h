@@ -114,6 +114,13 @@ int bmhrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, v
 int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                         float* dx, const float* dx_add /* optional: dx = dx_add + LN'(dy) */, float* dgamma,
                         float* dbeta, int64_t rows, int32_t D, bmhrl_stream_t stream);
+/* Same result; the column sums go block partials -> `workspace` -> dgamma/dbeta instead of every block adding into
+ * the same 2*D addresses.  workspace: bmhrl_layernorm_bwd_workspace(rows, D) floats, need not be initialised; with a
+ * NULL / too small workspace the call is bmhrl_layernorm_bwd. */
+int64_t bmhrl_layernorm_bwd_workspace(int64_t rows, int32_t D);
+int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, const float* dx_add, float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                           float* workspace, int64_t workspace_floats, bmhrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Feature add + positional encoding (K1): out = a (+ b) + PE[s]  (epoch_loops/captioning_bmrl_loops.py:498,

@@ -11,6 +11,9 @@ shapes = [  # (M, N, K, a_trans, b_trans, out, tag)
     (12800, 128, 3072, 0, 1, "f32", "A qkv dx"), (1024, 1024, 4096, 1, 1, "f32", "V dW"), (3072, 1024, 4096, 1, 1, "f32", "V qkv dW"),
     (3072, 128, 12800, 1, 1, "f32", "A qkv dW"), (128, 1024, 12800, 1, 1, "f32", "A out dW"), (10172, 364, 480, 1, 1, "f32", "vocab dW"),
     (800, 800, 256, 0, 0, "bf16x64", "attn S (A self)"), (800, 256, 800, 1, 1, "bf16x64", "attn dV (A self)"),
+    # caption-side GEMMs (B*L = 480 rows, d_model_caps 300): few blocks, latency bound
+    (480, 1024, 300, 0, 0, "bf16", "C q proj fwd"), (480, 300, 1024, 0, 0, "f32", "C out proj fwd"), (480, 1024, 1024, 0, 0, "bf16", "C 1024 fwd"),
+    (480, 300, 1024, 0, 1, "f32", "C q proj dx"), (480, 1024, 300, 0, 1, "bf16", "C out proj dx"), (4096, 2048, 300, 0, 0, "bf16", "KV(V) 300 fwd"),
 ]
 N_IT = 20
 for M, N, K, at, bt, out, tag in shapes:
