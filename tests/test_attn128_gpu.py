@@ -7,7 +7,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 4, 64, 64), (2, 4, 200, 130), (3, 2, 256, 800), (1, 4, 800, 800)])
+# (8, 4, ...): batch % 8 == 0 takes the "all (head, q-tile) of a batch row on one XCD" workgroup map; Sk = 20: the second
+# key half of the only tile is all padding; Sq = 70 / 200: ragged last q-tile (rows past Sq must not be stored)
+@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 4, 64, 64), (2, 4, 200, 130), (3, 2, 256, 800), (1, 4, 800, 800), (8, 4, 70, 200),
+                                       (16, 2, 96, 1024), (2, 4, 64, 20)])
 def test_shared128_attention_matches_torch(B, H, Sq, Sk):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -39,3 +42,28 @@ def test_shared128_attention_matches_torch(B, H, Sq, Sk):
     assert float((got[ok] - lse[ok]).abs().max()) < 2e-2
     if (~ok).any():                                # fully masked rows keep the exact fill value (backward relies on it)
         assert float((rmax[~ok] + 1e9).abs().max()) == 0.0 and float((rsum[~ok] - Sk).abs().max()) < 1e-3 * Sk
+
+
+def test_shared128_attention_strided_rows_and_no_mask():
+    """leading dimensions larger than the rows (the operands are column slices of wider buffers), mask = NULL; the
+    columns next to the output slice must stay untouched"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, Sq, Sk = 8, 4, 100, 300
+    g = torch.Generator().manual_seed(7)
+    Qw = (0.5 * torch.randn(B, Sq, H * 128 + 64, generator=g)).to(dev).to(torch.bfloat16)
+    Xw = torch.randn(B, Sk, 128 + 8, generator=g).to(dev).to(torch.bfloat16)
+    ctxw = torch.full((B, Sq, H * 128 + 16), 7.0, dtype=torch.bfloat16, device=dev)
+    rmax = torch.empty(B, H, Sq, device=dev)
+    rsum = torch.empty(B, H, Sq, device=dev)
+    scale = 1.0 / 16
+    ops.attention_shared128_fwd(Qw, Xw, ctxw, rmax, rsum, None, 0, B, H, Sq, Sk, scale, H * 128 + 64, 128 + 8, H * 128 + 16)
+    torch.cuda.synchronize()
+    Qp = Qw[..., :H * 128].float().view(B, Sq, H, 128)
+    X = Xw[..., :128].float()
+    p = torch.softmax(torch.einsum("bqhd,bkd->bhqk", Qp, X) * scale, -1)
+    ref = torch.einsum("bhqk,bkd->bqhd", p, X).reshape(B, Sq, H * 128)
+    assert float((ctxw[..., :H * 128].float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    assert float((ctxw[..., H * 128:].float() - 7.0).abs().max()) == 0.0

@@ -149,7 +149,8 @@ def _attn_ref(Q, K, V, mask, H, scale):
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,kind", [(2, 4, 64, 64, "none"), (2, 4, 70, 100, "pad"), (3, 2, 30, 37, "causal"),
-                                            (2, 4, 256, 800, "pad"), (2, 4, 800, 256, "pad"), (1, 4, 33, 130, "allmasked")])
+                                            (2, 4, 256, 800, "pad"), (2, 4, 800, 256, "pad"), (1, 4, 33, 130, "allmasked"),
+                                            (2, 4, 64, 20, "pad"), (3, 3, 100, 1500, "none")])
 def test_attention_fwd(dev, B, H, Sq, Sk, kind):
     from bmhrl_amd import ops
     dk = 256
@@ -193,6 +194,30 @@ def test_attention_fwd(dev, B, H, Sq, Sk, kind):
     assert float((s.max(-1).values.cpu() - rmax.double().cpu()).max()) < 8 * 0.6932 + 1e-3   # lag bound (2^8)
     if kind == "allmasked":  # uniform attention over all Sk keys (reference fills -1e9, not -inf)
         assert rel_err(O.float(), V.float().view(B, Sk, D).mean(1, keepdim=True).expand(B, Sq, D)) < 1.5e-2
+
+
+def test_attention_fwd_output_dropout(dev):
+    """dropout on the attention output (model/multihead_attention.py:27-28): every element is either dropped or the
+    undropped value / (1 - p); the pattern follows the seed"""
+    from bmhrl_amd import ops
+    B, H, Sq, Sk, dk = 2, 4, 96, 160, 256
+    D = H * dk
+    g = torch.Generator().manual_seed(11)
+    Q = bf(torch.randn(B, Sq, D, generator=g)).to(dev)
+    K = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    V = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    rmax = torch.empty(B, H, Sq, device=dev); rsum = torch.empty(B, H, Sq, device=dev)
+    outs = []
+    for p, seed in ((0.0, 0), (0.25, 5), (0.25, 5), (0.25, 6)):
+        O = torch.zeros(B, Sq, D, dtype=torch.bfloat16, device=dev)
+        ops.attention_fwd(Q, K, V, O, rmax, rsum, None, 0, 0, B, H, Sq, Sk, dk, 1 / 16, D, D, D, D, dropout_p=p, seed=seed)
+        outs.append(O.float())
+    base, d1, d1b, d2 = outs
+    assert torch.equal(d1, d1b) and not torch.equal(d1, d2)
+    kept = d1 != 0
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - 0.25) < 0.01
+    assert float((d1[kept] - base[kept] / 0.75).abs().max()) < 2e-2 * float(base.abs().max()) / 0.75
 
 
 def test_softmax_rows_and_delta(dev):
