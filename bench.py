@@ -169,8 +169,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BMHRL_BENCH_FORCE_PG=1: a one-rank RCCL process group (rehearses capture / replay next to RCCL's own threads and
+    # streams on a one-GPU box; with BMHRL_SPLIT_BACKWARD=1 the step takes the multi-rank path)
+    if world > 1 or os.environ.get("BMHRL_BENCH_FORCE_PG") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -232,7 +235,7 @@ def main():
             "loss": loss_v, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()      # rank 0 is still measuring the roofline kernel: keep the communicator alive until it is done
         dist.destroy_process_group()
 
