@@ -557,3 +557,44 @@ def discontinue_reward_loop(cider_diff: Tensor, gamma: float, n_step: int = 100,
         cd[b, old_l:l + 1] = disc
         old_l = l + 1
     return cd
+
+
+# --------------------------------------------------------------------------------------
+# Feature loader.  Pinned to the reference's own functions by tests/golden/loader.npz
+# (captioning_datasets/load_features.py imports only numpy / torch and runs here).
+# --------------------------------------------------------------------------------------
+def crop_a_segment_loop(feature: Tensor, start: float, end: float, duration: float) -> Optional[Tensor]:
+    """captioning_datasets/load_features.py:14-35: rows [int(S*start/duration), int(S*end/duration)) of a (S, D) stack; an
+    empty range becomes one row ([S:S] -> [S-1:S] at the very end, [i:i] -> [i:i+1] elsewhere); None when nothing is left
+    (e.g. start beyond the stack)."""
+    S = feature.shape[0]
+    a = int(S * (start / duration))
+    b = int(S * (end / duration))
+    if a == b:
+        if a == S:
+            a -= 1
+        else:
+            b += 1
+    out = feature[a:b, :]
+    return None if len(out) == 0 else out
+
+
+def batch_feature_stacks_loop(samples, pad_idx: float) -> Dict[str, Tensor]:
+    """captioning_datasets/captioning_dataset.py:262-290: `samples` is a list of (rgb, flow, audio) stacks, each (S_i, D)
+    or None for a clip whose file is missing / whose crop is empty (-> one zero row, :268-278).  rgb and audio are padded
+    to the longest clip of the batch with pad_idx, flow with 0 (it is summed onto rgb later)."""
+    rgb, flow, aud = [], [], []
+    for r, f, a in samples:
+        if r is None and f is None:
+            r, f = torch.zeros(1, 1024), torch.zeros(1, 1024)
+        if a is None:
+            a = torch.zeros(1, 128)
+        rgb.append(r.float()); flow.append(f.float()); aud.append(a.float())
+
+    def pad(seqs, value):
+        T = max(s.shape[0] for s in seqs)
+        out = torch.full((len(seqs), T, seqs[0].shape[1]), float(value))
+        for i, s in enumerate(seqs):
+            out[i, :s.shape[0]] = s
+        return out
+    return {"rgb": pad(rgb, pad_idx), "flow": pad(flow, 0.0), "audio": pad(aud, pad_idx)}

@@ -325,6 +325,76 @@ def rl_glue_cases():
     np.savez_compressed(os.path.join(HERE, "rl_glue.npz"), **out)
 
 
+def loader_clip_arrays(i):
+    """deterministic, compressible feature files of test clip i: (rgb, flow, audio) or None for a missing modality"""
+    S = [7, 12, 1, 9, 5, 10][i % 6]
+    Sa = [11, 4, 2, 15, 6, 3][i % 6]
+    r = (np.arange(S)[:, None] * 3 + (np.arange(1024)[None, :] % 5) + i).astype(np.float32)
+    f = (np.arange(S)[:, None] * 2 - (np.arange(1024)[None, :] % 3) + 0.5 * i).astype(np.float32)
+    a = (np.arange(Sa)[:, None] + (np.arange(128)[None, :] % 4) * 0.25 + i).astype(np.float32)
+    return r, f, a
+
+
+LOADER_CLIPS = [  # (index, start, end, duration, video files present, audio file present)
+    (0, 0.0, 10.0, 10.0, True, True), (1, 2.5, 7.0, 20.0, True, True), (2, 0.0, 0.3, 9.0, True, True),
+    (3, 8.9, 9.0, 9.0, True, True), (4, 1.0, 4.0, 5.0, False, True), (5, 3.0, 6.0, 12.0, True, False),
+    (1, 19.99, 20.0, 20.0, True, True), (3, 0.0, 0.01, 9.0, True, True)]
+
+
+def loader_cases():
+    """captioning_datasets/load_features.py (imports numpy / torch only): crop_a_segment over a grid incl. its edge cases,
+    and load_features_from_npy on files written here; the batch assembly (captioning_dataset.py:262-290: zero row for a
+    missing clip, pad_sequence with pad_idx / 0 / pad_idx) follows the reference line by line with torch's pad_sequence
+    -- that module itself imports torchtext and cannot be loaded."""
+    import importlib.util
+    from torch.nn.utils.rnn import pad_sequence
+    spec = importlib.util.spec_from_file_location("ref_load_features", os.path.join(REF, "captioning_datasets", "load_features.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    g = torch.Generator().manual_seed(23)
+    cases = []
+    for i in range(400):
+        S = int(torch.randint(1, 40, (1,), generator=g))
+        dur = float(torch.rand(1, generator=g)) * 200 + 1
+        a, b = sorted(float(x) for x in torch.rand(2, generator=g) * dur)
+        if i % 7 == 0:
+            b = a                                    # empty segment
+        if i % 11 == 0:
+            a, b = dur, dur                          # at the very end
+        if i % 13 == 0:
+            b = dur * 1.2                            # annotation past the end of the video
+        if i % 17 == 0:
+            a, b = dur * 1.1, dur * 1.3              # entirely past the end
+        feat = torch.arange(S, dtype=torch.float32)[:, None].expand(S, 2)
+        out = ref.crop_a_segment(feat, a, b, dur)
+        cases.append([S, a, b, dur, -1 if out is None else int(out[0, 0]), 0 if out is None else out.shape[0]])
+    res = {"crop": np.array(cases, dtype=np.float64)}
+    pad_idx = 1
+    with tempfile.TemporaryDirectory() as td:
+        cfg = SimpleNamespace(video_features_path=td, audio_features_path=td)
+        for i in range(6):
+            r, f, a = loader_clip_arrays(i)
+            present = [c for c in LOADER_CLIPS if c[0] == i]
+            if all(c[4] for c in present):
+                np.save(os.path.join(td, f"clip{i}_rgb.npy"), r)
+                np.save(os.path.join(td, f"clip{i}_flow.npy"), f)
+            if all(c[5] for c in present):
+                np.save(os.path.join(td, f"clip{i}.npy"), a)
+        rgbs, flows, auds = [], [], []
+        for i, start, end, dur, _, _ in LOADER_CLIPS:
+            st = ref.load_features_from_npy(cfg, ["i3d_features", "vggish_features"], f"clip{i}", start, end, dur, pad_idx)
+            r, f, a = st["rgb"], st["flow"], st["audio"]
+            if r is None and f is None:
+                r, f = ref.fill_missing_features("zero", 1024), ref.fill_missing_features("zero", 1024)
+            if a is None:
+                a = ref.fill_missing_features("zero", 128)
+            rgbs.append(r); flows.append(f); auds.append(a)
+        res["rgb"] = np_(pad_sequence(rgbs, batch_first=True, padding_value=pad_idx))
+        res["flow"] = np_(pad_sequence(flows, batch_first=True, padding_value=0))
+        res["audio"] = np_(pad_sequence(auds, batch_first=True, padding_value=pad_idx))
+    np.savez_compressed(os.path.join(HERE, "loader.npz"), **res)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -336,6 +406,7 @@ if __name__ == "__main__":
     sample_clip_decode()
     detr_cases()
     rl_glue_cases()
+    loader_cases()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

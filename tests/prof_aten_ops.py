@@ -12,12 +12,13 @@ b = syn.synthetic_batch(16, 256, 800, 30, 10172, seed=0)
 fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}; cap = b["captions"].to(dev)
 for _ in range(3): tr.step(fs, cap)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     tr.step(fs, cap)
     torch.cuda.synchronize()
-ka = prof.key_averages(group_by_stack_n=6)
+ka = prof.key_averages(group_by_stack_n=12)
 rows = [e for e in ka if e.key.startswith("aten::") and e.device_time_total > 0]
 rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:45]:
-    st = [s for s in e.stack if "bmhrl_amd" in s or "train.py" in s][:2]
-    print(f"{e.key:28s} n={e.count:3d} dev={e.device_time_total:8.1f}us  " + " | ".join(s.split('/')[-1][:60] for s in st))
+    st = [s for s in e.stack if "bmhrl_amd" in s or "train.py" in s][:3]
+    print(f"{e.key:22s} n={e.count:3d} dev={e.device_time_total:7.1f}us  " + " | ".join(s.split('/')[-1][:55] for s in st))

@@ -1,0 +1,103 @@
+"""Feature loader on the host: the oracle restatement and bmhrl_amd.loader against fixtures generated from the
+reference's own captioning_datasets/load_features.py (tests/golden/make_golden.py: loader_cases)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bmhrl_amd.loader import Clip, FeaturePacker, crop_bounds
+from oracle import bmhrl_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "loader.npz"))
+
+# the fixture's input files are a deterministic function of the clip index (same formulas as make_golden.loader_clip_arrays)
+CLIPS = [(0, 0.0, 10.0, 10.0, True, True), (1, 2.5, 7.0, 20.0, True, True), (2, 0.0, 0.3, 9.0, True, True),
+         (3, 8.9, 9.0, 9.0, True, True), (4, 1.0, 4.0, 5.0, False, True), (5, 3.0, 6.0, 12.0, True, False),
+         (1, 19.99, 20.0, 20.0, True, True), (3, 0.0, 0.01, 9.0, True, True)]
+
+
+def clip_arrays(i):
+    S = [7, 12, 1, 9, 5, 10][i % 6]
+    Sa = [11, 4, 2, 15, 6, 3][i % 6]
+    r = (np.arange(S)[:, None] * 3 + (np.arange(1024)[None, :] % 5) + i).astype(np.float32)
+    f = (np.arange(S)[:, None] * 2 - (np.arange(1024)[None, :] % 3) + 0.5 * i).astype(np.float32)
+    a = (np.arange(Sa)[:, None] + (np.arange(128)[None, :] % 4) * 0.25 + i).astype(np.float32)
+    return r, f, a
+
+
+def write_files(td):
+    for i in range(6):
+        r, f, a = clip_arrays(i)
+        present = [c for c in CLIPS if c[0] == i]
+        if all(c[4] for c in present):
+            np.save(os.path.join(td, f"clip{i}_rgb.npy"), r)
+            np.save(os.path.join(td, f"clip{i}_flow.npy"), f)
+        if all(c[5] for c in present):
+            np.save(os.path.join(td, f"clip{i}.npy"), a)
+
+
+def test_crop_matches_reference_grid():
+    for S, a, b, dur, first, n in G["crop"]:
+        S, first, n = int(S), int(first), int(n)
+        feat = torch.arange(S, dtype=torch.float32)[:, None].expand(S, 2)
+        got = O.crop_a_segment_loop(feat, a, b, dur)
+        assert (got is None) == (n == 0)
+        if n:
+            assert int(got[0, 0]) == first and got.shape[0] == n
+        r = crop_bounds(S, a, b, dur)
+        assert (r is None) == (n == 0)
+        if n:
+            assert r == (first, first + n)
+
+
+def test_batch_matches_reference(tmp_path):
+    write_files(str(tmp_path))
+    # oracle: per-clip stacks with the restated crop, then the restated batch assembly
+    samples = []
+    for i, start, end, dur, has_v, has_a in CLIPS:
+        r, f, a = clip_arrays(i)
+        r_ = O.crop_a_segment_loop(torch.from_numpy(r), start, end, dur) if has_v else None
+        f_ = O.crop_a_segment_loop(torch.from_numpy(f), start, end, dur) if has_v else None
+        a_ = O.crop_a_segment_loop(torch.from_numpy(a), start, end, dur) if has_a else None
+        samples.append((r_, f_, a_))
+    ob = O.batch_feature_stacks_loop(samples, pad_idx=1)
+    for k in ("rgb", "flow", "audio"):
+        assert ob[k].shape == G[k].shape and np.array_equal(ob[k].numpy(), G[k]), k
+    # product: packed straight from the memory-mapped files
+    packer = FeaturePacker(str(tmp_path), str(tmp_path), pad_idx=1, pin=False)
+    got = packer.pack([Clip(f"clip{i}", "a caption", s, e, d) for i, s, e, d, _, _ in CLIPS])
+    for k in ("rgb", "flow", "audio"):
+        assert got[k].dtype == torch.float32 and tuple(got[k].shape) == G[k].shape
+        assert np.array_equal(got[k].numpy(), G[k]), k
+
+
+def test_staging_is_reused_and_slots_are_independent(tmp_path):
+    write_files(str(tmp_path))
+    packer = FeaturePacker(str(tmp_path), str(tmp_path), pad_idx=1, pin=False)
+    c = [Clip(f"clip{i}", "", s, e, d) for i, s, e, d, _, _ in CLIPS]
+    a0 = packer.pack(c[:4], slot=0)
+    keep = {k: v.clone() for k, v in a0.items()}
+    b1 = packer.pack(c[4:], slot=1)                      # the other slot: slot 0's tensors stay intact
+    for k in keep:
+        assert torch.equal(a0[k], keep[k])
+    a0b = packer.pack(c[:2], slot=0)                     # a smaller batch reuses (a prefix of) the same staging memory
+    assert a0b["rgb"].data_ptr() == a0["rgb"].data_ptr()
+    assert b1["rgb"].data_ptr() != a0["rgb"].data_ptr()
+
+
+def test_single_modality_and_shape_mismatch(tmp_path):
+    write_files(str(tmp_path))
+    packer = FeaturePacker(str(tmp_path), str(tmp_path), pad_idx=1, modality="video", pin=False)
+    got = packer.pack([Clip("clip0", "", 0.0, 10.0, 10.0)])
+    assert tuple(got["audio"].shape) == (1, 1, 128) and float(got["audio"].abs().sum()) == 0.0   # audio not read: zero row
+    np.save(os.path.join(str(tmp_path), "clip0_flow.npy"), np.zeros((3, 1024), np.float32))
+    with pytest.raises(AssertionError):                  # load_features.py:79 `assert stack_rgb.shape == stack_flow.shape`
+        packer.pack([Clip("clip0", "", 0.0, 10.0, 10.0)])
+
+
+def test_device_batcher_refuses_cpu():
+    from bmhrl_amd.loader import DeviceBatcher
+    with pytest.raises(RuntimeError):
+        DeviceBatcher(FeaturePacker("x", "y", 1, pin=False), torch.device("cpu"))
