@@ -5,8 +5,8 @@
 
 Only the hot-path modules are aliased (model.bm_hrl_agent, model.blocks, model.multihead_attention, model.masking,
 model.encoder, model.decoder, model.utils,
-loss.label_smoothing, loss.biased_kl, epoch_loops.captioning_bmrl_loops); everything else keeps resolving to the
-reference's own files."""
+loss.label_smoothing, loss.biased_kl, epoch_loops.captioning_bmrl_loops, captioning_datasets.load_features); everything
+else keeps resolving to the reference's own files."""
 import importlib
 import sys
 import types
@@ -22,11 +22,12 @@ ALIASES = {
     "loss.label_smoothing": "bmhrl_amd.loss.label_smoothing",
     "loss.biased_kl": "bmhrl_amd.loss.biased_kl",
     "epoch_loops.captioning_bmrl_loops": "bmhrl_amd.epoch_loops.captioning_bmrl_loops",
+    "captioning_datasets.load_features": "bmhrl_amd.loader",
 }
 
 
 def install():
-    for pkg in ("model", "loss", "epoch_loops"):
+    for pkg in ("model", "loss", "epoch_loops", "captioning_datasets"):
         if pkg not in sys.modules:
             try:
                 importlib.import_module(pkg)          # the reference's package, when it is on sys.path

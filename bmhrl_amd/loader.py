@@ -43,6 +43,69 @@ def crop_bounds(S: int, start: float, end: float, duration: float) -> Optional[T
     return (lo, hi) if hi > lo else None
 
 
+# ---- the reference's per-clip functions under their own names and signatures (captioning_datasets/load_features.py), for
+# callers that still assemble batches themselves (the reference's dataset class after `import bmhrl_amd.install`)
+def fill_missing_features(method, feature_size):
+    """load_features.py:8-12"""
+    if method == 'random':
+        return torch.rand(1, feature_size)
+    if method == 'zero':
+        return torch.zeros(1, feature_size).float()
+
+
+def crop_a_segment(feature, start, end, duration):
+    """load_features.py:14-35 on a (S, D) tensor or array: the kept rows (a view), or None"""
+    r = crop_bounds(feature.shape[0], start, end, duration)
+    return None if r is None else feature[r[0]:r[1], :]
+
+
+def pad_segment(feature, max_feature_len, pad_idx):
+    """load_features.py:38-44: rows appended up to max_feature_len with pad_idx"""
+    S, D = feature.shape
+    assert S <= max_feature_len
+    out = feature.new_full((max_feature_len, D), pad_idx)
+    out[:S] = feature
+    return out
+
+
+def load_features_from_npy(cfg, feature_names_list, video_id, start, end, duration, pad_idx, get_full_feat=False,
+                           is_vatex=False):
+    """load_features.py:47-99, same returns ({'audio','rgb','flow'[,'orig_feat_length']}, fp32 CPU tensors or None for a
+    missing file); the crop reads only its rows from the memory-mapped file."""
+    supported = {'i3d_features', 'vggish_features'}
+    assert isinstance(feature_names_list, list) and len(feature_names_list) > 0 and set(feature_names_list).issubset(supported)
+    stacks = {}
+    if get_full_feat:
+        stacks['orig_feat_length'] = {}
+
+    def read(path, full_key, full_len, full_pad):
+        m = _open(path)
+        if m is None:
+            return None
+        if get_full_feat:
+            stacks['orig_feat_length'][full_key] = m.shape[0]
+            return pad_segment(torch.from_numpy(np.array(m, dtype=np.float32)), full_len, full_pad)
+        r = crop_bounds(m.shape[0], start, end, duration)
+        return None if r is None else torch.from_numpy(np.array(m[r[0]:r[1]], dtype=np.float32))
+
+    if 'vggish_features' in feature_names_list:
+        apath = './data/vggish_vatex/' if is_vatex else cfg.audio_features_path
+        stacks['audio'] = read(os.path.join(apath, f'{video_id}.npy'), 'audio',
+                               cfg.pad_feats_up_to['audio'] if get_full_feat else 0, pad_idx)
+    if 'i3d_features' in feature_names_list:
+        vpath = './data/i3d_vatex/' if is_vatex else cfg.video_features_path
+        rgb_m, flow_m = _open(os.path.join(vpath, f'{video_id}_rgb.npy')), _open(os.path.join(vpath, f'{video_id}_flow.npy'))
+        if rgb_m is None or flow_m is None:            # one try block in the reference: either file missing drops both
+            stacks['rgb'] = stacks['flow'] = None
+        else:
+            assert rgb_m.shape == flow_m.shape
+            stacks['rgb'] = read(os.path.join(vpath, f'{video_id}_rgb.npy'), 'rgb',
+                                 cfg.pad_feats_up_to['video'] if get_full_feat else 0, pad_idx)
+            stacks['flow'] = read(os.path.join(vpath, f'{video_id}_flow.npy'), 'flow',
+                                  cfg.pad_feats_up_to['video'] if get_full_feat else 0, 0)
+    return stacks
+
+
 class Clip:
     """one row of the meta table: what `__getitem__` reads per index (captioning_dataset.py:251-253)"""
     __slots__ = ("video_id", "caption", "start", "end", "duration")

@@ -389,6 +389,10 @@ def loader_cases():
             if a is None:
                 a = ref.fill_missing_features("zero", 128)
             rgbs.append(r); flows.append(f); auds.append(a)
+        cfg.pad_feats_up_to = {"video": 14, "audio": 16}
+        full = ref.load_features_from_npy(cfg, ["i3d_features", "vggish_features"], "clip1", 0, 1, 1, pad_idx, get_full_feat=True)
+        res["full_rgb"], res["full_flow"], res["full_audio"] = np_(full["rgb"]), np_(full["flow"]), np_(full["audio"])
+        res["full_len"] = np.array([full["orig_feat_length"][k] for k in ("rgb", "flow", "audio")])
         res["rgb"] = np_(pad_sequence(rgbs, batch_first=True, padding_value=pad_idx))
         res["flow"] = np_(pad_sequence(flows, batch_first=True, padding_value=0))
         res["audio"] = np_(pad_sequence(auds, batch_first=True, padding_value=pad_idx))

@@ -101,3 +101,35 @@ def test_device_batcher_refuses_cpu():
     from bmhrl_amd.loader import DeviceBatcher
     with pytest.raises(RuntimeError):
         DeviceBatcher(FeaturePacker("x", "y", 1, pin=False), torch.device("cpu"))
+
+
+def test_reference_named_functions(tmp_path):
+    """captioning_datasets.load_features.{load_features_from_npy, crop_a_segment, pad_segment, fill_missing_features} under
+    their own names (what `import bmhrl_amd.install` puts at that module path)"""
+    from types import SimpleNamespace
+    from bmhrl_amd import loader as L
+    write_files(str(tmp_path))
+    cfg = SimpleNamespace(video_features_path=str(tmp_path), audio_features_path=str(tmp_path), pad_feats_up_to={"video": 14, "audio": 16})
+    names = ["i3d_features", "vggish_features"]
+    for b, (i, start, end, dur, has_v, has_a) in enumerate(CLIPS):
+        st = L.load_features_from_npy(cfg, names, f"clip{i}", start, end, dur, 1)
+        for k, present in (("rgb", has_v), ("flow", has_v), ("audio", has_a)):
+            if not present:
+                assert st[k] is None
+                continue
+            n = st[k].shape[0]
+            assert st[k].dtype == torch.float32 and np.array_equal(st[k].numpy(), G[k][b, :n])
+    full = L.load_features_from_npy(cfg, names, "clip1", 0, 1, 1, 1, get_full_feat=True)
+    for k in ("rgb", "flow", "audio"):
+        assert np.array_equal(full[k].numpy(), G["full_" + k])
+    assert [full["orig_feat_length"][k] for k in ("rgb", "flow", "audio")] == list(G["full_len"])
+    assert float(L.fill_missing_features("zero", 128).abs().sum()) == 0.0 and tuple(L.fill_missing_features("random", 7).shape) == (1, 7)
+    with pytest.raises(AssertionError):
+        L.load_features_from_npy(cfg, ["resnet"], "clip1", 0, 1, 1, 1)
+
+
+def test_install_aliases_the_loader():
+    import importlib
+    import bmhrl_amd.install  # noqa: F401
+    m = importlib.import_module("captioning_datasets.load_features")
+    assert m.load_features_from_npy.__module__ == "bmhrl_amd.loader"
