@@ -247,12 +247,20 @@ def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, ms
     ops.gemm(Qb, Kb, Sq, Sk, dk, lda=ldq, ldb=ldk, a_off=q_off, b_off=k_off, batch=(B, H), a_strides=(Sq * ldq, dk),
              b_strides=(Sk * ldk, dk), C_f32=S, ldc=Sk, c_strides=(H * Sq * Sk, Sq * Sk), alpha=scale, mask=mask,
              mask_sb1=msb, mask_sm=msq)
-    P = torch.zeros(B, H, Sq, Skp, dtype=_BF16, device=dev)
+    P = _padded_bf16(B * H * Sq, Sk, dev).view(B, H, Sq, Skp)
     ops.softmax_rows(S, Sk, P, Skp, B * H * Sq, Sk)
     ops.gemm(P, Vb, Sq, dk, Sk, lda=Skp, ldb=ldv, b_off=v_off, b_trans=True, batch=(B, H),
              a_strides=(H * Sq * Skp, Sq * Skp), b_strides=(Sk * ldv, dk), C_bf16=O, ldcb=D, cb_strides=(Sq * D, dk),
              dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev, drop_strides=(Sq * D, dk, D))
     return O, ("mat", P)
+
+
+def _padded_bf16(rows, cols, dev):
+    """(rows, pad8(cols)) bf16 operand whose padding columns are zero and whose body the caller overwrites: no padding ->
+    uninitialised memory; padded -> a pooled buffer of the step (zeroed once when created, kernels never write the padding)"""
+    if cols % 8 == 0:
+        return torch.empty(rows, cols, dtype=_BF16, device=dev)
+    return SCRATCH.bf16(rows, cols, dev)
 
 
 def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, dQb, dq_off, lddq, dKb, dk_off, lddk,
@@ -272,13 +280,13 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     ops.attn_delta(dOb, D, Ob, D, delta, B, H, Sq, dk, scale=1.0 - p_drop)
     pstr = (H * Sq * Skp, Sq * Skp)
     if stats[0] == "flash":
-        P = torch.zeros(B, H, Sq, Skp, dtype=_BF16, device=dev) if Skp != Sk else torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)
+        P = _padded_bf16(B * H * Sq, Sk, dev).view(B, H, Sq, Skp)
         ops.gemm(Qb, Kb, Sq, Sk, dk, lda=ldq, ldb=ldk, a_off=q_off, b_off=k_off, batch=(B, H), a_strides=(Sq * ldq, dk),
                  b_strides=(Sk * ldk, dk), C_bf16=P, ldcb=Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
                  mask=mask, mask_sb1=msb, mask_sm=msq, rowvec=stats[1], rowvec2=stats[2], rv_strides=(H * Sq, Sq))
     else:
         P = stats[1]
-    dS = torch.zeros(B, H, Sq, Skp, dtype=_BF16, device=dev) if Skp != Sk else torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)
+    dS = _padded_bf16(B * H * Sq, Sk, dev).view(B, H, Sq, Skp)
     ops.gemm(dOb, Vb, Sq, Sk, dk, lda=D, ldb=ldv, b_off=v_off, batch=(B, H), a_strides=(Sq * D, dk),
              b_strides=(Sk * ldv, dk), C_bf16=dS, ldcb=Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale,
              rowvec=delta, rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=pstr)
@@ -546,7 +554,7 @@ class MemAttnFn(torch.autograd.Function):
             ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
                      b_strides=(Sk * dmp, 0), C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8,
                      mask_sb1=msb, mask_sm=msq)
-            P = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+            P = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
             ops.softmax_rows(S, Skp, P, Skp, B * L * H, Sk)
             # context in memory space (B, L, H, dm) = P_h mem
             ops.gemm(P, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=(L * H * Skp, Skp),
@@ -595,10 +603,10 @@ class MemAttnFn(torch.autograd.Function):
         # softmax backward: delta = sum_k P dP = sum_n dCx Cx ; dS = P (dP - delta) * scale with dP = dCx_h mem^T
         delta = torch.empty(B, H, L, device=dev)
         ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B, H, L, dmp)
-        dS = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+        dS = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
         pstr = (L * H * Skp, Skp)
         if flash:      # P (B, L, H, Sk) recomputed from the statistics of the fused forward
-            P = (torch.zeros if Skp != Sk else torch.empty)(B, L, H, Skp, dtype=_BF16, device=dev)
+            P = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
             ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
                      b_strides=(Sk * dmp, 0), C_bf16=P, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
                      mask=m8, mask_sb1=msb, mask_sm=0, rowvec=stats[0], rowvec2=stats[1], rv_strides=(H * L, L))
