@@ -130,10 +130,10 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   constexpr int MERGE_FLOATS = (KW - 1) * QW * (OREGS + 2) * 64;
   static_assert(MERGE_FLOATS * 4 <= LDS_KV, "the merge area reuses the K/V stages");
   constexpr int MAXT = MAXK / BN;              // key tiles
-  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_KV + 2 * MAXK * 4 + MAXT * 8];
+  __shared__ __attribute__((aligned(16))) char smem_raw[LDS_KV + 2 * MAXK * 4 + (MAXT / 4 + 4) * 8];
   float* s_coef = reinterpret_cast<float*>(smem_raw + LDS_KV);
   float* s_pen = s_coef + MAXK;
-  uint64_t* s_slow = reinterpret_cast<uint64_t*>(s_pen + MAXK);   // per tile: lanes (keys) with pen != 0
+  uint64_t* s_slow = reinterpret_cast<uint64_t*>(s_pen + MAXK);   // per 4 tiles: a byte per (tile, key half) with pen != 0
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -228,15 +228,28 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   auto issue_v = [&](int t, int buf) { issue_tile(Vgb, v_next, p.ldv, voffb, 0, t, smem + (2 + buf) * VST + wrow * DK); };
   issue_k(0, 0);          // with Q and the mask bytes: what the first S^T chain needs; V(0) and K(1) follow below
   BMHRL_STAMP(1)
-  // key-mask bytes of this thread's keys, all requested before the first use (one exposed latency, shared with Q and the
-  // first K/V stages, instead of one per 256 keys)
-  constexpr int NCO = (MAXK + NT - 1) / NT;
-  uint8_t mk[NCO];
+  // key-mask bytes: a thread owns FOUR consecutive keys per pass (one 32-bit load when the row is 4-byte aligned), all
+  // passes requested before the first use (one exposed latency, shared with Q and the first K/V stage)
+  constexpr int NCO = (MAXK + 4 * NT - 1) / (4 * NT);
+  uint32_t mk[NCO];
   if constexpr (key_mask) {
+    const uint8_t* mrow_b = p.mask ? p.mask + (long)b * p.mask_sb : nullptr;
+    const bool al4 = (reinterpret_cast<uintptr_t>(mrow_b) & 3) == 0;          // uniform
 #pragma unroll
     for (int j = 0; j < NCO; ++j) {
-      const int i = tid + NT * j;
-      mk[j] = (p.mask != nullptr && i < p.Sk) ? p.mask[(long)b * p.mask_sb + i] : (uint8_t)1;
+      const int i0 = 4 * (tid + NT * j);
+      uint32_t v = 0x01010101u;                                               // no mask / keys past Sk: "keep" (pen handles Sk)
+      if (mrow_b != nullptr && i0 < p.Sk) {
+        if (al4 && i0 + 4 <= p.Sk) {
+          v = *reinterpret_cast<const uint32_t*>(mrow_b + i0);
+        } else {
+          v = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (i0 + e < p.Sk) v |= (uint32_t)mrow_b[i0 + e] << (8 * e);
+        }
+      }
+      mk[j] = v;
     }
   }
 
@@ -253,22 +266,28 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   }
 
   BMHRL_STAMP(2)
-  // per-key coefficients; the 64 keys a wave handles in pass j are exactly tile 4j + wave, so one ballot per pass tells
-  // which (tile, key half) pairs need the per-key path
+  // per-key coefficients, four keys per lane and pass.  A wave covers 256 keys = 4 tiles per pass (16 lanes per tile, 8
+  // per key half), so ONE ballot of "some key of mine needs the per-key path" holds a byte per (tile, key half).
 #pragma unroll
   for (int j = 0; j < NCO; ++j) {
-    const int i = tid + NT * j;
-    const bool in = i < p.Sk;
-    bool keep = in;
-    if constexpr (key_mask) keep = in && mk[j] != 0;
-    const float pen = in ? ((keep || !key_mask) ? 0.f : NEG_MASK * LOG2E) : -INFINITY;
-    if (i < nt * BN) {
-      s_coef[i] = (in && (keep || !key_mask)) ? p.scale * LOG2E : 0.f;
-      s_pen[i] = pen;
+    const int i0 = 4 * (tid + NT * j);
+    f32x4 cf, pn;
+    bool any_slow = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool in = i0 + e < p.Sk;
+      bool keep = in;
+      if constexpr (key_mask) keep = in && ((mk[j] >> (8 * e)) & 0xffu) != 0;
+      cf[e] = (in && (keep || !key_mask)) ? p.scale * LOG2E : 0.f;
+      pn[e] = in ? ((keep || !key_mask) ? 0.f : NEG_MASK * LOG2E) : -INFINITY;
+      any_slow |= pn[e] != 0.f;
     }
-    const uint64_t bal = __ballot(pen != 0.f);
-    const int tile = (NT / BN) * j + wave_s * 64 / BN;
-    if (lane == 0 && tile < nt) s_slow[tile] = bal;
+    if (i0 < nt * BN) {                                  // nt * BN is a multiple of 4
+      *reinterpret_cast<f32x4*>(s_coef + i0) = cf;
+      *reinterpret_cast<f32x4*>(s_pen + i0) = pn;
+    }
+    const uint64_t bal = __ballot(any_slow);
+    if (lane == 0) s_slow[(NT / 64) * j + wave_s] = bal;  // word w: tiles 4w .. 4w+3
   }
 
   f32x16 o[DK / 32];
@@ -457,9 +476,9 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   if constexpr (QMASK) {
     slow_bits = ~0ull;
   } else {
-    static_assert(BN == 64 && MAXT <= 64, "one ballot word per tile, one lane per tile");
-    const uint64_t w = lane < nt ? s_slow[lane] : 0ull;
-    slow_bits = __ballot((unsigned)(w >> (32 * ki)) != 0u);
+    static_assert(BN == 64 && MAXT <= 64 && NT == 256, "a ballot word per 4 tiles (a byte per tile and key half), a lane per tile");
+    const uint64_t w = lane < nt ? s_slow[lane >> 2] : 0ull;
+    slow_bits = __ballot(((w >> (16 * (lane & 3) + 8 * ki)) & 0xffull) != 0ull);
   }
   {
     f32x4 cf[4], pn[4];

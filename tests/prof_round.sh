@@ -12,8 +12,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/attn256 -- python3 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/tests/bench_one_attn128.py > $OUT/fetch.log 2>&1 || { tail -3 $OUT/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/tests/bench_one_attn128.py > $OUT/write.log 2>&1 || { tail -3 $OUT/write.log; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eager -- python3 $R/bench.py --eager --steps 8 --warmup 2 --no-cpu-baseline > $OUT/eager.log 2>&1 || { tail -3 $OUT/eager.log; exit 1; }
+# the bench command itself under the tracer (graph mode): its last phase launches the roofline kernel 55 times in isolation
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/benchtrace -- python3 $R/bench.py --no-cpu-baseline > $OUT/benchtrace.log 2>&1 || { tail -3 $OUT/benchtrace.log; exit 1; }
 cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -3 $OUT/bench.err; exit 1; }
+python3 profiles/bench_trace_summary.py $OUT/benchtrace $OUT/benchtrace.log > $OUT/bench_kernel_stats.md
 python3 profiles/summarize.py $OUT/eager 10 > $OUT/eager_stats.md
 python3 - <<PY
 import csv, glob, collections
