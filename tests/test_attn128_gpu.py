@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 # (8, 4, ...): batch % 8 == 0 takes the "all (head, q-tile) of a batch row on one XCD" workgroup map; Sk = 20: the second
 # key half of the only tile is all padding; Sq = 70 / 200: ragged last q-tile (rows past Sq must not be stored)
 @pytest.mark.parametrize("B,H,Sq,Sk", [(2, 4, 64, 64), (2, 4, 200, 130), (3, 2, 256, 800), (1, 4, 800, 800), (8, 4, 70, 200),
-                                       (16, 2, 96, 1024), (2, 4, 64, 20)])
+                                       (16, 2, 96, 1024), (2, 4, 64, 20),
+                                       (16, 4, 256, 800), (16, 4, 800, 800)])     # the bench workload's V<-A and audio self attention
 def test_shared128_attention_matches_torch(B, H, Sq, Sk):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -67,3 +68,34 @@ def test_shared128_attention_strided_rows_and_no_mask():
     ref = torch.einsum("bhqk,bkd->bqhd", p, X).reshape(B, Sq, H * 128)
     assert float((ctxw[..., :H * 128].float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
     assert float((ctxw[..., H * 128:].float() - 7.0).abs().max()) == 0.0
+
+
+def test_shared128_masked_keys_do_not_matter_and_key_order_is_free():
+    """size-independent properties at the bench shape: rows of X at masked keys can hold anything (bit-identical output),
+    and permuting the keys (with their mask) changes the result only by rounding"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, Sq, Sk = 16, 4, 256, 800
+    g = torch.Generator().manual_seed(5)
+    Qp = (0.5 * torch.randn(B, Sq, H, 128, generator=g)).to(dev).to(torch.bfloat16)
+    X = torch.randn(B, Sk, 128, generator=g).to(dev).to(torch.bfloat16)
+    mask = (torch.rand(B, Sk, generator=g) > 0.2).to(dev)
+    mask[:, 0] = True
+
+    def run(Xi, mi):
+        ctx = torch.empty(B, Sq, H, 128, dtype=torch.bfloat16, device=dev)
+        rmax = torch.empty(B, H, Sq, device=dev); rsum = torch.empty(B, H, Sq, device=dev)
+        ops.attention_shared128_fwd(Qp, Xi.contiguous(), ctx, rmax, rsum, mi.contiguous(), Sk, B, H, Sq, Sk, 1 / 16, H * 128, 128, H * 128)
+        return ctx.float(), rmax + torch.log(rsum)
+
+    base, lse = run(X, mask)
+    X2 = X.clone()
+    X2[~mask] = 37.0                                    # garbage (finite) at the masked keys
+    other, lse2 = run(X2, mask)
+    assert torch.equal(base, other) and torch.equal(lse, lse2)
+    perm = torch.randperm(Sk, generator=g).to(dev)
+    pout, plse = run(X[:, perm], mask[:, perm])
+    assert float((pout - base).abs().max()) < 2e-2 * float(base.abs().max())
+    assert float((plse - lse).abs().max()) < 2e-3
