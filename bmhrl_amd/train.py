@@ -53,18 +53,34 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
 
+    def set_buckets(self, counts: List[int]):
+        """consecutive runs of `counts[i]` parameters form bucket i, in the order backward completes their gradients"""
+        assert sum(counts) == len(self.params) and all(c >= 0 for c in counts)
+        self.bucket_bounds = [0]
+        for c in counts:
+            self.bucket_bounds.append(self.bucket_bounds[-1] + c)
+        self.n_early = counts[0]
+        self.split_off = self._elem_off(self.bucket_bounds[1])       # first element of bucket 1
+
     def set_split(self, n_early: int):
-        """the first n_early parameters form bucket 0 (their gradients are complete early in backward), the rest bucket 1"""
-        self.n_early = n_early
-        self.split_off = self.offsets[n_early] if n_early < len(self.params) else self.n
+        """two buckets: the first n_early parameters (gradients complete early in backward) and the rest"""
+        self.set_buckets([n_early, len(self.params) - n_early])
+
+    def _elem_off(self, param_index: int) -> int:
+        return self.offsets[param_index] if param_index < len(self.params) else self.n
+
+    def _bucket_range(self, part):
+        if part is None:
+            return 0, len(self.params)
+        return self.bucket_bounds[part], self.bucket_bounds[part + 1]
 
     def gather_grads(self, part=None):
         """copy the autograd gradients into the flat bucket; missing ones stay zero.  On the GPU this is ONE launch of the
         segmented copy kernel (bmhrl_cast_segments, fp32 mode): inside a trainer step the gradients live at fixed
         addresses (slices of the step scratch arena), so the segment table is built once and reused.
-        part: None = all parameters, 0 / 1 = one of the two buckets of set_split()."""
+        part: None = all parameters, i = bucket i of set_buckets() / set_split()."""
         dst, src, missing = [], [], []
-        lo, hi = (0, len(self.params)) if part is None else ((0, self.n_early) if part == 0 else (self.n_early, len(self.params)))
+        lo, hi = self._bucket_range(part)
         for p, gv in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             if p.grad is None:
                 missing.append(gv)
@@ -99,9 +115,10 @@ class FlatAdam:
         return 1.0
 
     def all_reduce_part(self, part: int, group=None):
-        """asynchronous all-reduce (sum) of one bucket of set_split(); returns the work handle (None without a group)"""
+        """asynchronous all-reduce (sum) of one bucket; returns the work handle (None without a group)"""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            lo, hi = (0, self.split_off) if part == 0 else (self.split_off, self.n)
+            plo, phi = self._bucket_range(part)
+            lo, hi = self._elem_off(plo), self._elem_off(phi)
             if hi > lo:
                 return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
         return None
@@ -163,14 +180,23 @@ class CaptionTrainer:
         # all-reduce of the first bucket overlaps the encoder's backward (split_backward).
         names = {id(p): n for n, p in self.agent.named_parameters()}
         bucket = trainable_bucket(self.agent)
+        # Backward reaches the encoder layers last, the last layer first: phases = [everything downstream of the encoder,
+        # encoder layer N-1, ..., encoder layer 0]; the all-reduce of a phase's bucket overlaps the next phase's backward.
         early = [p for p in bucket if not names[id(p)].startswith("bm_enc.")]
-        late = [p for p in bucket if names[id(p)].startswith("bm_enc.")]
-        self.opt = FlatAdam(early + late, lr=lr, weight_decay=weight_decay)
-        self.opt.set_split(len(early))
-        self.early_params, self.late_params = early, late
+        enc_layers = list(self.agent.bm_enc.encoder.layers)
+        n_enc = len(enc_layers)
+        per_layer = [[p for p in bucket if names[id(p)].startswith(f"bm_enc.encoder.layers.{i}.")] for i in range(n_enc)]
+        claimed = {id(p) for lp in per_layer for p in lp}
+        per_layer[0] += [p for p in bucket if names[id(p)].startswith("bm_enc.") and id(p) not in claimed]
+        self.phase_params = [early] + [per_layer[i] for i in reversed(range(n_enc))]
+        self.opt = FlatAdam([p for ph in self.phase_params for p in ph], lr=lr, weight_decay=weight_decay)
+        self.opt.set_buckets([len(ph) for ph in self.phase_params])
+        self.early_params = early
+        self.n_enc = n_enc
         self.split_backward = None          # None: split when a process group with more than one rank is active
-        self._enc_out = None
-        self.agent.bm_enc.register_forward_hook(lambda mod, inp, out: setattr(self, "_enc_out", out))
+        self._layer_out = {}
+        for i, layer in enumerate(enc_layers):   # (V-stream, A-stream) after layer i: the cut between two backward phases
+            layer.register_forward_hook(lambda mod, inp, out, i=i: self._layer_out.__setitem__(i, out))
         self.modality = "audio_video"
         self.graph = None
         self.static = None
@@ -220,7 +246,8 @@ class CaptionTrainer:
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._graph_body_a()
                 if self._split():
-                    self._graph_body_a2()
+                    for j in range(1, self.n_enc + 1):
+                        self._graph_body_phase(j)
                 self._graph_body_b(self.opt.all_reduce())   # warm-up steps are real steps: replicas stay identical
             SHADOWS.refresh()                 # builds the segment table of the one-launch shadow refresh (a host -> device
                                               # copy, not allowed while capturing); the captured body reuses it
@@ -237,9 +264,12 @@ class CaptionTrainer:
             self.graph = True
             return
         if self._split():
-            self.graph_a2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool()):
-                self._graph_body_a2()
+            self.graph_a2 = []                # one graph per encoder layer, in backward order
+            for j in range(1, self.n_enc + 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph_a.pool()):
+                    self._graph_body_phase(j)
+                self.graph_a2.append(g)
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
             self._graph_body_b(self._world_scale())
@@ -268,12 +298,12 @@ class CaptionTrainer:
         SHADOWS.refresh()
         loss, _ = self._forward_loss(st, trg_in, trg_y)
         if self._split():
-            # phase 1 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)
-            enc_out = list(self._enc_out)
-            outs = torch.autograd.grad(loss, self.early_params + enc_out, retain_graph=True, allow_unused=True)
+            # phase 0 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)
+            cut = list(self._layer_out[self.n_enc - 1])
+            outs = torch.autograd.grad(loss, self.early_params + cut, retain_graph=True, allow_unused=True)
             for p, g in zip(self.early_params, outs):
                 p.grad = g
-            self._enc_grads = (enc_out, list(outs[len(self.early_params):]))
+            self._cut = (cut, list(outs[len(self.early_params):]))
             self.opt.gather_grads(0)
         else:
             loss.backward()
@@ -281,14 +311,23 @@ class CaptionTrainer:
             SCRATCH.end_step()
         self.static_loss.copy_(loss.detach())
 
-    def _graph_body_a2(self):
-        """phase 2 of the backward (split mode): the encoder, from the gradients of its two outputs"""
-        enc_out, enc_grads = self._enc_grads
-        pairs = [(t, g) for t, g in zip(enc_out, enc_grads) if g is not None]
-        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs], inputs=self.late_params)
-        self._enc_grads = self._enc_out = None
-        self.opt.gather_grads(1)
-        SCRATCH.end_step()
+    def _graph_body_phase(self, j: int):
+        """phase j = 1..n_enc of the backward (split mode): encoder layer n_enc - j, from the gradients of its outputs
+        to its parameters and to the outputs of the layer below"""
+        idx = self.n_enc - j
+        cut, gcut = self._cut
+        pairs = [(t, g) for t, g in zip(cut, gcut) if g is not None]
+        params = self.phase_params[j]
+        below = list(self._layer_out[idx - 1]) if idx > 0 else []
+        outs = torch.autograd.grad([t for t, _ in pairs], params + below, grad_outputs=[g for _, g in pairs],
+                                   retain_graph=idx > 0, allow_unused=True)
+        for p, g in zip(params, outs):
+            p.grad = g
+        self._cut = (below, list(outs[len(params):])) if idx > 0 else None
+        self.opt.gather_grads(j)
+        if idx == 0:
+            self._layer_out.clear()
+            SCRATCH.end_step()
 
     def _graph_body_b(self, scale):
         self.opt.step(scale)
@@ -302,10 +341,11 @@ class CaptionTrainer:
         if self.graph_b is None:                  # single process: forward, backward and Adam are one graph
             return self.static_loss
         if self._split():
-            w0 = self.opt.all_reduce_part(0)      # overlaps the encoder backward below
-            self.graph_a2.replay()
-            w1 = self.opt.all_reduce_part(1)
-            for w in (w0, w1):
+            works = [self.opt.all_reduce_part(0)]             # overlaps the encoder backward below
+            for j, g in enumerate(self.graph_a2, start=1):
+                g.replay()
+                works.append(self.opt.all_reduce_part(j))     # layer by layer: only the first layer's bucket is exposed
+            for w in works:
                 if w is not None:
                     w.wait()
         else:

@@ -1,5 +1,5 @@
-"""Two-phase backward of the trainer (data-parallel runs: the all-reduce of the non-encoder bucket overlaps the encoder's
-backward).  On one GPU the split must reproduce the single-phase step: same losses and parameters."""
+"""Phased backward of the trainer (data-parallel runs: head + fusion stacks, then one phase per encoder layer; the all-reduce
+of a phase's gradient bucket overlaps the next phase's backward).  On one GPU the split must reproduce the single-phase step: same losses and parameters."""
 import pytest
 import torch
 
@@ -24,6 +24,9 @@ def test_split_backward_equals_single_phase():
         t.capture(fs, cap, warmup=2)
         losses = [float(t.replay()) for _ in range(3)]
         assert hasattr(t, "graph_a2") == split
+        if split:
+            assert len(t.graph_a2) == 2 and len(t.opt.bucket_bounds) == 4          # N = 2 encoder layers -> 3 buckets
+            assert all(b > a for a, b in zip(t.opt.bucket_bounds, t.opt.bucket_bounds[1:]))
         runs.append((losses, t.opt.flat.clone(), t.opt.split_off, t.opt.n))
     (l0, p0, _, _), (l0b, p0b, _, _), (l1, p1, off, n) = runs
     assert 0 < off < n                                   # both buckets are non-empty
