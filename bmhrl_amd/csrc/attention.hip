@@ -701,26 +701,34 @@ __global__ __launch_bounds__(NT, DK == 128 ? 2 : 1) void attn_fwd_kernel(const A
   BMHRL_STAMP(10)
 }
 
+// delta[b,h,q] = scale * sum_d dO[b,q,h,d] * O[b,q,h,d].  RPW (b,q,h) rows per wave, 64 / RPW lanes each, 16 bytes per lane and
+// step: a head of 128 (256) columns keeps every lane busy with RPW = 4 (2) instead of 16 (32) of 64.
+template <int RPW>
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, long lddo, const bf16_t* __restrict__ O, long ldo,
                                   float* __restrict__ delta, float scale, int B, int H, int Sq, int dk) {
-  // one wave per (b, q, h)
+  constexpr int LPR = 64 / RPW;                       // lanes per row
+  const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR;
   const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long total = (long)B * Sq * H;
-  if (wid >= total) return;
-  const int lane = threadIdx.x & 63;
-  const int hd = wid % H;
-  const long bq = wid / H;
-  const bf16_t* a = dO + bq * lddo + (long)hd * dk;
-  const bf16_t* c = O + bq * ldo + (long)hd * dk;
+  const long row = wid * RPW + sub;
   float acc = 0.f;
-  for (int d = lane * 8; d < dk; d += 64 * 8) {
-    const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + d);
-    const bf16x8 y = *reinterpret_cast<const bf16x8*>(c + d);
+  if (row < total) {
+    const int hd = row % H;
+    const long bq = row / H;
+    const bf16_t* a = dO + bq * lddo + (long)hd * dk;
+    const bf16_t* c = O + bq * ldo + (long)hd * dk;
+    for (int d = l * 8; d < dk; d += LPR * 8) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + d);
+      const bf16x8 y = *reinterpret_cast<const bf16x8*>(c + d);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+      for (int j = 0; j < 8; ++j) acc += (float)x[j] * (float)y[j];
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);   // stays inside the row's lane group
+  if (l == 0 && row < total) {
+    const int hd = row % H;
+    const long bq = row / H;
     const long b = bq / Sq, q = bq % Sq;
     delta[(b * H + hd) * Sq + q] = acc * scale;
   }
@@ -816,9 +824,14 @@ extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int
                                 int32_t B, int32_t H, int32_t Sq, int32_t dk, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(dO && O && delta && dk % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0);
   const long total = (long)B * Sq * H;
-  dim3 grid((unsigned)((total + 3) / 4)), block(256);
-  hipLaunchKernelGGL(attn_delta_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dO, (long)lddo,
-                     (const bf16_t*)O, (long)ldo, delta, scale, B, H, Sq, dk);
+  dim3 block(256);
+#define BMHRL_DELTA(RPW_)                                                                                              \
+  hipLaunchKernelGGL(attn_delta_kernel<RPW_>, dim3((unsigned)((total + 4 * RPW_ - 1) / (4 * RPW_))), block, 0,          \
+                     (hipStream_t)stream, (const bf16_t*)dO, (long)lddo, (const bf16_t*)O, (long)ldo, delta, scale, B, H, Sq, dk)
+  if (dk <= 128) BMHRL_DELTA(4);
+  else if (dk <= 256) BMHRL_DELTA(2);
+  else BMHRL_DELTA(1);
+#undef BMHRL_DELTA
   return hip_status(hipGetLastError());
 }
 
