@@ -40,27 +40,37 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 
 // Same, D % 4 == 0 and aligned: the row is read once with 16-byte loads and kept in registers (NV groups of 4 columns per
 // lane), mean / variance come from the registers, the bf16 output leaves as 8-byte stores.
-template <int NV>
+// RPW rows per wave (64 / RPW lanes each): rows of <= 128 columns (the audio stream) would otherwise leave half of every
+// wave idle and need twice the waves.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of LPR lanes, on every lane
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+template <int NV, int RPW>
 __global__ void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                   bf16_t* __restrict__ yb, long ldy, float* __restrict__ yf, float* __restrict__ mean,
                                   float* __restrict__ rstd, long rows, int D) {
-  const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const float* xr = x + row * D;
+  static_assert(RPW == 1 || NV == 1, "several rows per wave only for rows that fit one 4-column group per lane");
+  constexpr int LPR = 64 / RPW;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR;
+  const long row = ((long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * RPW + sub;
+  const bool valid = row < rows;                       // (lanes of a missing row still take part in the shuffles)
+  const float* xr = x + (valid ? row : 0) * D;
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = 4 * lane + 256 * i;
-    v[i] = c < D ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int c = 4 * l + 4 * LPR * i;
+    v[i] = (valid && c < D) ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
-  const float mu = wave_sum(s) / D;
+  const float mu = group_sum<LPR>(s) / D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = 4 * lane + 256 * i;
+    const int c = 4 * l + 4 * LPR * i;
     if (c < D) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -69,14 +79,15 @@ __global__ void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __re
       }
     }
   }
-  const float rs = rsqrtf(wave_sum(q) / D + 1e-5f);
-  if (lane == 0) {
+  const float rs = rsqrtf(group_sum<LPR>(q) / D + 1e-5f);
+  if (!valid) return;
+  if (l == 0) {
     if (mean) mean[row] = mu;
     if (rstd) rstd[row] = rs;
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = 4 * lane + 256 * i;
+    const int c = 4 * l + 4 * LPR * i;
     if (c < D) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
       f32x4 y;
@@ -377,19 +388,21 @@ __global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg)
 }
 
 // y = bf16(x * scale * dropout) AND colsum[n] += sum_m y[m][n] in one pass (dY cast + bias gradient of the same layer).
-// Block = 256 columns x `rows_per_block` rows; thread = (4-column group, row lane 0..3); one atomic per column per block.
+// Block = up to 256 columns x `rows_per_block` rows; thread = (4-column group, row lane).  `cgs` (power of two <= 64) column
+// groups cover the block's columns and the other 256 / cgs thread rows take rows in parallel, so a narrow matrix (the
+// 128-wide audio stream: cgs = 32, 8 row lanes) keeps all threads busy; one atomic per column per block.
 __global__ void cast_colsum_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows, int cols,
                                    float scale, float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev,
-                                   float* __restrict__ colsum, int rows_per_block) {
-  __shared__ float red[4][256];
+                                   float* __restrict__ colsum, int rows_per_block, int cgs) {
+  __shared__ float red[1024];                       // [row lane][4 * cgs]
   const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
-  const int cg = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int cg = threadIdx.x % cgs, ry = threadIdx.x / cgs, rl = 256 / cgs;
   const int col = blockIdx.x * 256 + cg * 4;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const bool vec = (ldx & 3) == 0 && (ldy & 3) == 0 && col + 4 <= cols && (((uintptr_t)x & 15) | ((uintptr_t)y & 7)) == 0;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (col < cols) {
-    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += 4) {
+    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += rl) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (vec) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(x + r * ldx + col);
@@ -410,10 +423,16 @@ __global__ void cast_colsum_kernel(const float* __restrict__ x, long ldx, bf16_t
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) red[ry][cg * 4 + j] = acc[j];
+  for (int j = 0; j < 4; ++j) red[ry * (4 * cgs) + cg * 4 + j] = acc[j];
   __syncthreads();
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < cols) atomicAdd(colsum + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if ((int)threadIdx.x < 4 * cgs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) {
+      float t = 0.f;
+      for (int k = 0; k < rl; ++k) t += red[k * (4 * cgs) + threadIdx.x];
+      atomicAdd(colsum + c, t);
+    }
+  }
 }
 
 // db[n] (+)= sum_m dY[m][n]: a block covers 512 columns x `rows_per_block` rows; thread = (column group of 8 bf16 =
@@ -558,9 +577,12 @@ extern "C" int bmhrl_layernorm_fwd(const float* x, const float* gamma, const flo
                    ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_f32) & 15) == 0) && (((uintptr_t)y_bf16 & 7) == 0);
   if (vec) {
     const int nv = (D + 255) / 256;
-#define LN_FWDV(NV_) hipLaunchKernelGGL(ln_fwd_vec_kernel<NV_>, grid, block, 0, S_(stream), x, gamma, beta, (bf16_t*)y_bf16, \
-                                        (long)ldy, y_f32, mean, rstd, (long)rows, D)
-    if (nv <= 1) LN_FWDV(1); else if (nv <= 2) LN_FWDV(2); else LN_FWDV(4);
+#define LN_FWDV(NV_, RPW_, GRID_) hipLaunchKernelGGL((ln_fwd_vec_kernel<NV_, RPW_>), GRID_, block, 0, S_(stream), x, gamma, beta, \
+                                                    (bf16_t*)y_bf16, (long)ldy, y_f32, mean, rstd, (long)rows, D)
+    if (D <= 128) {                                      // two rows per wave
+      dim3 grid2((unsigned)((rows + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK)));
+      LN_FWDV(1, 2, grid2);
+    } else if (nv <= 1) LN_FWDV(1, 1, grid); else if (nv <= 2) LN_FWDV(2, 1, grid); else LN_FWDV(4, 1, grid);
 #undef LN_FWDV
     return hip_status(hipGetLastError());
   }
@@ -696,11 +718,17 @@ extern "C" int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int6
                                       bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(x && y && colsum && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
   const int col_blocks = (cols + 255) / 256;
-  int rpb = (int)((rows * col_blocks + 511) / 512);      // aim at ~512 blocks in total
+  // ~512 blocks in total, but at most 128 row blocks: every block ends with one atomic per column, and atomics onto the
+  // same address serialise (a 128-wide matrix cut into 512 row blocks spent 13 of its 16 us there)
+  int row_blocks = 512 / col_blocks;
+  row_blocks = row_blocks < 1 ? 1 : (row_blocks > 128 ? 128 : row_blocks);
+  int rpb = (int)((rows + row_blocks - 1) / row_blocks);
   if (rpb < 16) rpb = 16;
   dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  int cgs = 64;                                         // column groups per block: the smallest power of two covering it
+  while (cgs > 1 && (cgs / 2) * 4 >= (cols < 256 ? cols : 256)) cgs /= 2;
   hipLaunchKernelGGL(cast_colsum_kernel, grid, block, 0, S_(stream), x, (long)ldx, (bf16_t*)y, (long)ldy, (long)rows, cols,
-                     scale, dropout_p, seed, seed_dev, colsum, rpb);
+                     scale, dropout_p, seed, seed_dev, colsum, rpb, cgs);
   return hip_status(hipGetLastError());
 }
 

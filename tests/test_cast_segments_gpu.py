@@ -62,7 +62,7 @@ def test_cast_colsum_and_gemm_epilogue_colsum():
     from bmhrl_amd import ops
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(1)
-    for rows, cols in ((480, 300), (4096, 1024), (37, 5)):
+    for rows, cols in ((480, 300), (4096, 1024), (37, 5), (12800, 128), (1000, 64), (333, 20), (64, 600)):
         x = torch.randn(rows, cols, generator=g).to(dev)
         y = torch.zeros(rows, ops.pad8(cols), dtype=torch.bfloat16, device=dev)
         cs = torch.zeros(cols, device=dev)

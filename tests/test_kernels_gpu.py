@@ -237,7 +237,7 @@ def test_softmax_rows_and_delta(dev):
     assert rel_err(delta, ref) < 1e-5
 
 
-@pytest.mark.parametrize("rows,D", [(4096, 1024), (12800, 128), (480, 300), (33, 20)])
+@pytest.mark.parametrize("rows,D", [(4096, 1024), (12800, 128), (480, 300), (33, 20), (1001, 128), (7, 64), (130, 96)])
 def test_layernorm(dev, rows, D):
     from bmhrl_amd import ops
     g = torch.Generator().manual_seed(rows + D)
