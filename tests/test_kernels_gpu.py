@@ -416,6 +416,24 @@ def test_loss_kernels_vs_oracle(dev, golden):
     assert rel_err(x.grad, torch.from_numpy(g["reinforce_grad_logits"])) < 1e-5
 
 
+@pytest.mark.parametrize("rows,V", [(480, 10172), (7, 10171), (33, 1024), (5, 4100), (3, 12288), (2, 12292), (9, 52)])
+def test_log_softmax_fwd_bwd_paths(dev, rows, V):
+    """register-resident rows (V % 4 == 0, V <= 12 288) and the strided fallback (odd or longer rows)"""
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(rows * 7 + V)
+    logits = (3 * torch.randn(rows, V, generator=g)).to(dev)
+    lp = logits.clone()
+    ops.log_softmax_(lp, V, rows, V)
+    ref = torch.log_softmax(logits.double(), -1)
+    assert float((lp.double() - ref).abs().max()) < 2e-5
+    dlogp = torch.randn(rows, V, generator=g).to(dev)
+    gb = ops.bf16_zeros(rows, V, dev)
+    ops.log_softmax_bwd(dlogp, lp, V, gb, gb.shape[1], rows, V)
+    want = dlogp.double() - ref.exp() * dlogp.double().sum(-1, keepdim=True)
+    assert float((gb[:, :V].double() - want).abs().max()) < 1e-2 * float(want.abs().max())
+    assert float(gb[:, V:].float().abs().sum()) == 0.0          # padding columns untouched
+
+
 def test_sampling(dev):
     from bmhrl_amd import ops
     V, rows = 1000, 4096
