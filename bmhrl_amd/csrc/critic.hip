@@ -121,6 +121,91 @@ __global__ __launch_bounds__(256) void rnn_step_kernel(const float* __restrict__
   }
 }
 
+// ---- layer wavefront.  Cell (layer l, time t) needs (l-1, t) and (l, t-1) only, so launch s runs every cell with
+// l + t == s at once (blockIdx.z = layer): L + n_layers - 1 = 35 launches of up to 6 x 150 blocks instead of 6 x (1 + 30)
+// small ones in a row.  The input projection of the cell (W_ih x_t + b_ih [+ b_hh]) moves into the step: same k-ordered
+// fmaf chain and the same association (chain + (b_ih + b_hh), then + the recurrent chain) as the GEMM + step pair above.
+constexpr int MAX_RNN_LAYERS = 8;
+struct RnnTable { bmhrl_rnn_layer l[MAX_RNN_LAYERS]; };
+
+__global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n_layers, int B, int L, int H, int s) {
+  // x_t / h_{t-1} of the 16 batch rows go through LDS (every gate row of the block needs them); the weight rows do not:
+  // a row belongs to one gate-row slot, its 16 batch lanes read the same 16 bytes (one broadcast fetch), nothing is reused,
+  // so staging them would only add a pass and keep the block count per CU at one.
+  __shared__ __attribute__((aligned(16))) float sh_h[16][MAXH + 4];
+  __shared__ float sh_g[16][17], sh_x[16][17];
+  const int layer = blockIdx.z, t = s - layer;
+  if (t < 0 || t >= L) return;                      // uniform for the block
+  const bmhrl_rnn_layer& P = tab.l[layer];
+  const int GATES = P.gates;
+  const int tid = threadIdx.x;
+  const int u0 = blockIdx.x * UB, b0 = blockIdx.y * 16;
+  const int slot = tid >> 4, bl = tid & 15;
+  const int gate = slot / UB, unit = u0 + slot % UB;
+  const bool row_ok = gate < GATES && unit < H;
+  const long wrow = (long)(row_ok ? gate * H + unit : 0);
+  auto chain = [&](const float* __restrict__ w, const int K) {        // sum_k w[k] * sh_h[bl][k], k ascending
+    float acc = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < K; k += 4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(&sh_h[bl][k]);
+      acc = fmaf(wv[0], xv[0], acc); acc = fmaf(wv[1], xv[1], acc); acc = fmaf(wv[2], xv[2], acc); acc = fmaf(wv[3], xv[3], acc);
+    }
+    return acc;
+  };
+  // pass 1: x_t (16 batch rows)
+  const int K = P.in_dim;
+  for (int i = tid; i < 16 * (K / 4); i += 256) {
+    const int r = i / (K / 4), c4 = (i % (K / 4)) * 4;
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+    if (b0 + r < B) xv = *reinterpret_cast<const f32x4*>(P.in_seq + ((long)(b0 + r) * L + t) * P.in_ld + c4);
+    *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = xv;
+  }
+  __syncthreads();
+  float xp = 0.f;
+  if (row_ok) xp = chain(P.w_ih + wrow * K, K) + (P.b_ih[wrow] + (GATES == 4 ? P.b_hh[wrow] : 0.f));
+  __syncthreads();
+  // pass 2: h_{t-1}
+  const float* h_prev = P.h[(t + 1) & 1];
+  for (int i = tid; i < 16 * (H / 4); i += 256) {
+    const int r = i / (H / 4), c4 = (i % (H / 4)) * 4;
+    f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+    if (b0 + r < B && t > 0) hv = *reinterpret_cast<const f32x4*>(h_prev + (long)(b0 + r) * H + c4);
+    *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = hv;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  if (row_ok && t > 0) acc = chain(P.w_hh + wrow * H, H);
+  if (row_ok && GATES == 3) acc += P.b_hh[wrow];
+  sh_g[slot][bl] = acc;
+  sh_x[slot][bl] = xp;
+  __syncthreads();
+  if (tid < UB * 16) {
+    const int u = u0 + (tid >> 4), b = b0 + bl;
+    if (u < H && b < B) {
+      const int ul = tid >> 4;
+      float hn;
+      if (GATES == 4) {
+        const float gi = sigmoidf_(sh_x[ul][bl] + sh_g[ul][bl]);
+        const float gf = sigmoidf_(sh_x[UB + ul][bl] + sh_g[UB + ul][bl]);
+        const float gg = tanhf(sh_x[2 * UB + ul][bl] + sh_g[2 * UB + ul][bl]);
+        const float go = sigmoidf_(sh_x[3 * UB + ul][bl] + sh_g[3 * UB + ul][bl]);
+        const float c = gf * (t > 0 ? P.c[(t + 1) & 1][(long)b * H + u] : 0.f) + gi * gg;
+        P.c[t & 1][(long)b * H + u] = c;
+        hn = go * tanhf(c);
+      } else {
+        const float r = sigmoidf_(sh_x[ul][bl] + sh_g[ul][bl]);
+        const float z = sigmoidf_(sh_x[UB + ul][bl] + sh_g[UB + ul][bl]);
+        const float n = tanhf(sh_x[2 * UB + ul][bl] + r * sh_g[2 * UB + ul][bl]);
+        hn = (1.f - z) * n + z * (t > 0 ? sh_h[bl][u] : 0.f);
+      }
+      P.h[t & 1][(long)b * H + u] = hn;
+      P.seq_out[((long)b * L + t) * H + u] = P.arelu_alpha ? arelu_(hn, P.arelu_alpha[0], P.arelu_beta[0]) : hn;
+    }
+  }
+}
+
 // labels[row] = sigmoid(lin_w . x[row] + lin_b) > thr ; also the raw score (for tests / callers)
 __global__ void critic_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                    float thr, float* __restrict__ score, int32_t* __restrict__ labels, long rows, int H) {
@@ -163,6 +248,25 @@ extern "C" int bmhrl_rnn_step(int32_t gates, const float* xproj, const float* wh
   else
     hipLaunchKernelGGL(rnn_step_kernel<3>, grid, block, 0, S_(stream), xproj, whh, bhh, h_prev, c_prev, h_out, c_out, seq_out,
                        arelu_alpha, arelu_beta, B, L, H, t);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_layers, int32_t B, int32_t L, int32_t H,
+                                   bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(layers && n_layers > 0 && n_layers <= MAX_RNN_LAYERS && B > 0 && L > 0 && H > 0 && H <= MAXH && H % 4 == 0);
+  RnnTable tab;
+  for (int i = 0; i < n_layers; ++i) {
+    const bmhrl_rnn_layer& p = layers[i];
+    BMHRL_CHECK_ARG((p.gates == 3 || p.gates == 4) && p.w_ih && p.w_hh && p.b_ih && p.b_hh && p.in_seq && p.seq_out && p.h[0] && p.h[1]);
+    BMHRL_CHECK_ARG(p.in_dim > 0 && p.in_dim <= MAXH && p.in_dim % 4 == 0 && p.in_ld % 4 == 0 && p.in_ld >= p.in_dim);
+    BMHRL_CHECK_ARG(p.gates == 3 || (p.c[0] && p.c[1]));
+    BMHRL_CHECK_ARG((p.arelu_alpha == nullptr) == (p.arelu_beta == nullptr));
+    BMHRL_CHECK_ARG((((uintptr_t)p.w_ih | (uintptr_t)p.w_hh | (uintptr_t)p.in_seq | (uintptr_t)p.h[0] | (uintptr_t)p.h[1]) & 15) == 0);
+    tab.l[i] = p;
+  }
+  dim3 grid((unsigned)((H + UB - 1) / UB), (unsigned)((B + 15) / 16), (unsigned)n_layers), block(256);
+  for (int s = 0; s < L + n_layers - 1; ++s)
+    hipLaunchKernelGGL(rnn_wave_kernel, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s);
   return hip_status(hipGetLastError());
 }
 

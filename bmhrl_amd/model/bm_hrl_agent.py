@@ -223,31 +223,51 @@ class SegmentCritic(nn.Module):
             h, _ = self.gru(self.relu(h))
             return self.lin(self.relu2(h))
 
+    wavefront = True       # False: one GEMM + L step launches per layer (the first native form; kept for A/B and tests)
+
     def score_and_labels(self, emb, threshold):
-        """HIP path: fp32 input projections on the f32 MFMA + one small launch per (layer, time step).
-        Returns (score (B, L, 1), labels (B, L) int32 = sigmoid(score) > threshold)."""
+        """HIP path, fp32.  Returns (score (B, L, 1), labels (B, L) int32 = sigmoid(score) > threshold).
+        The six recurrent layers run as a wavefront over (layer, time) (ops.rnn_wavefront: L + 5 launches, every cell of
+        a diagonal in one grid, input projection fused into the cell) instead of layer after layer (6 x (1 + L))."""
         from .. import ops
         B, L, d = emb.shape
         dev = emb.device
         H = self.lstm.hidden_size
         rows = B * L
         x = emb.detach().contiguous().view(rows, d)
-        hb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
-        cb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
-        for kind, rnn, gates, n_layers, act in (("lstm", self.lstm, 4, 4, self.relu), ("gru", self.gru, 3, 2, self.relu2)):
-            for l in range(n_layers):
-                w_ih, w_hh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
-                b_ih, b_hh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
-                K = x.shape[1]
-                xproj = torch.empty(rows, gates * H, device=dev)
-                ops.gemm_f32(x, w_ih, b_ih, b_hh if gates == 4 else None, xproj, rows, gates * H, K)
-                seq = torch.empty(rows, H, device=dev)
-                last = l == n_layers - 1
-                for t in range(L):
-                    ops.rnn_step(gates, xproj, w_hh, b_hh if gates == 3 else None, hb[(t + 1) & 1], cb[(t + 1) & 1], hb[t & 1],
-                                 cb[t & 1] if gates == 4 else None, seq, act.alpha if last else None,
-                                 act.beta if last else None, B, L, H, t)
-                x = seq
+        stacks = (("lstm", self.lstm, 4, 4, self.relu), ("gru", self.gru, 3, 2, self.relu2))
+        if self.wavefront and d % 4 == 0:
+            layers = []
+            for kind, rnn, gates, n_layers, act in stacks:
+                for l in range(n_layers):
+                    last = l == n_layers - 1
+                    seq = torch.empty(rows, H, device=dev)
+                    layers.append(dict(
+                        w_ih=getattr(rnn, f"weight_ih_l{l}"), w_hh=getattr(rnn, f"weight_hh_l{l}"),
+                        b_ih=getattr(rnn, f"bias_ih_l{l}"), b_hh=getattr(rnn, f"bias_hh_l{l}"),
+                        in_seq=x, in_ld=x.shape[1], in_dim=x.shape[1], gates=gates, seq_out=seq,
+                        h=[torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)],
+                        c=[torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)] if gates == 4 else None,
+                        arelu_alpha=act.alpha if last else None, arelu_beta=act.beta if last else None))
+                    x = seq
+            ops.rnn_wavefront(layers, B, L, H)
+        else:
+            hb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+            cb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+            for kind, rnn, gates, n_layers, act in stacks:
+                for l in range(n_layers):
+                    w_ih, w_hh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
+                    b_ih, b_hh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
+                    K = x.shape[1]
+                    xproj = torch.empty(rows, gates * H, device=dev)
+                    ops.gemm_f32(x, w_ih, b_ih, b_hh if gates == 4 else None, xproj, rows, gates * H, K)
+                    seq = torch.empty(rows, H, device=dev)
+                    last = l == n_layers - 1
+                    for t in range(L):
+                        ops.rnn_step(gates, xproj, w_hh, b_hh if gates == 3 else None, hb[(t + 1) & 1], cb[(t + 1) & 1], hb[t & 1],
+                                     cb[t & 1] if gates == 4 else None, seq, act.alpha if last else None,
+                                     act.beta if last else None, B, L, H, t)
+                    x = seq
         score = torch.empty(B, L, 1, device=dev)
         labels = torch.empty(B, L, dtype=torch.int32, device=dev)
         ops.critic_head(x, self.lin.weight, self.lin.bias, float(threshold), score, labels, rows, H)

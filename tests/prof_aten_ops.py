@@ -22,3 +22,10 @@ rows.sort(key=lambda e: -e.device_time_total)
 for e in rows[:45]:
     st = [s for s in e.stack if "bmhrl_amd" in s or "train.py" in s][:3]
     print(f"{e.key:22s} n={e.count:3d} dev={e.device_time_total:7.1f}us  " + " | ".join(s.split('/')[-1][:55] for s in st))
+
+print("\n-- copies by call site (count, whether or not device time was attributed to the operator)")
+cp = [e for e in ka if e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy")]
+cp.sort(key=lambda e: -e.count)
+for e in cp[:30]:
+    st = [s for s in e.stack if "bmhrl_amd" in s or "train.py" in s or "autograd" in s][:3]
+    print(f"{e.key:18s} n={e.count:3d}  " + " | ".join(s.split('/')[-1][:60] for s in st))

@@ -16,13 +16,15 @@ def _critic(cfg, dev):
     return c.to(dev)
 
 
-def test_critic_matches_reference_fixture(golden):
+@pytest.mark.parametrize("wavefront", [True, False])
+def test_critic_matches_reference_fixture(golden, wavefront):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
     g = golden("critic")
     cfg = syn.tiny_cfg()
     c = _critic(cfg, dev)
+    c.wavefront = wavefront
     emb = torch.from_numpy(g["emb"]).to(dev)
     score, labels = c.score_and_labels(emb, 0.25)
     ref = torch.from_numpy(g["out"])
@@ -31,13 +33,15 @@ def test_critic_matches_reference_fixture(golden):
     assert torch.equal(c(emb).cpu(), score.cpu())        # module call == reference forward signature
 
 
-def test_critic_full_width_vs_oracle():
+@pytest.mark.parametrize("wavefront", [True, False])
+def test_critic_full_width_vs_oracle(wavefront):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import bmhrl_oracle as O
     dev = torch.device("cuda:0")
     cfg = syn.default_cfg()
     c = _critic(cfg, dev)
+    c.wavefront = wavefront
     g = torch.Generator().manual_seed(3)
     emb = torch.randn(16, 30, 300, generator=g) * 17.3      # embeddings are scaled by sqrt(300) in the agent
     sd = {"critic." + k: v for k, v in syn.synthetic_critic_state(300, seed=1).items()}
@@ -47,3 +51,20 @@ def test_critic_full_width_vs_oracle():
     margin = (ref.squeeze(-1) - float(np.log(0.25 / 0.75))).abs()
     ok = margin > 1e-4                                      # labels must agree wherever the score is not on the threshold
     assert torch.equal(labels.cpu()[ok], O.segment_labels(ref, 0.25)[ok])
+
+
+@pytest.mark.parametrize("B,L", [(16, 30), (3, 7), (33, 2), (1, 1)])
+def test_wavefront_equals_layer_by_layer(B, L):
+    """the (layer, time) wavefront with the fused input projection keeps the arithmetic order of the GEMM + step form:
+    same scores to the last bits, identical labels; batch > 16 (two batch blocks), single step, single row"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    c = _critic(syn.default_cfg(), dev)
+    emb = (torch.randn(B, L, 300, generator=torch.Generator().manual_seed(B * 100 + L)) * 17.3).to(dev)
+    c.wavefront = True
+    s1, l1 = c.score_and_labels(emb, 0.25)
+    c.wavefront = False
+    s0, l0 = c.score_and_labels(emb, 0.25)
+    assert float((s1 - s0).abs().max()) <= 2e-6 * max(1.0, float(s0.abs().max()))
+    assert torch.equal(l1, l0)
