@@ -144,15 +144,48 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   const int gate = slot / UB, unit = u0 + slot % UB;
   const bool row_ok = gate < GATES && unit < H;
   const long wrow = (long)(row_ok ? gate * H + unit : 0);
-  auto chain = [&](const float* __restrict__ w, const int K) {        // sum_k w[k] * sh_h[bl][k], k ascending
-    float acc = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < K; k += 4) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(&sh_h[bl][k]);
-      acc = fmaf(wv[0], xv[0], acc); acc = fmaf(wv[1], xv[1], acc); acc = fmaf(wv[2], xv[2], acc); acc = fmaf(wv[3], xv[3], acc);
+  // y[b] = sum_k w[k] * sh_h[b][k] for the 16 batch rows of the block.  The 16 lanes of a gate-row slot split the row:
+  // lane j owns the 16-byte pieces j, j + 16, ... (coalesced 256-byte reads, all of a lane's <= 10 pieces requested at
+  // once: one memory latency per row instead of a chain of them), accumulates its slice against all 16 batch rows
+  // (x from LDS) and the 16 x 16 partial sums are reduce-scattered with 15 shuffles so that lane j ends with batch row j.
+  // (fixed summation order; it differs from a k-ascending chain by fp32 rounding only)
+  auto project = [&](const float* __restrict__ w, const int K) {
+    constexpr int NP = (MAXH / 4 + 15) / 16;            // pieces per lane (10)
+    const int nf = K / 4;
+    f32x4 wv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int f = bl + 16 * i;
+      wv[i] = f < nf ? *reinterpret_cast<const f32x4*>(w + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    return acc;
+    float acc[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) acc[b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int f = bl + 16 * i;
+      if (f < nf) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(&sh_h[b][4 * f]);
+          acc[b] = fmaf(wv[i][0], xv[0], acc[b]); acc[b] = fmaf(wv[i][1], xv[1], acc[b]);
+          acc[b] = fmaf(wv[i][2], xv[2], acc[b]); acc[b] = fmaf(wv[i][3], xv[3], acc[b]);
+        }
+      }
+    }
+    // reduce-scatter over the 16 lanes of the slot: after the step with mask m a lane keeps the batch rows whose bit m
+    // equals its own
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const bool hi = (bl & m) != 0;
+#pragma unroll
+      for (int b = 0; b < m; ++b) {
+        const float send = hi ? acc[b] : acc[b + m];
+        const float keep = hi ? acc[b + m] : acc[b];
+        acc[b] = keep + __shfl_xor(send, m, 64);
+      }
+    }
+    return acc[0];
   };
   // pass 1: x_t (16 batch rows)
   const int K = P.in_dim;
@@ -164,7 +197,8 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   }
   __syncthreads();
   float xp = 0.f;
-  if (row_ok) xp = chain(P.w_ih + wrow * K, K) + (P.b_ih[wrow] + (GATES == 4 ? P.b_hh[wrow] : 0.f));
+  xp = project(P.w_ih + wrow * K, K);               // (every lane takes part in the shuffles)
+  if (row_ok) xp += P.b_ih[wrow] + (GATES == 4 ? P.b_hh[wrow] : 0.f);
   __syncthreads();
   // pass 2: h_{t-1}
   const float* h_prev = P.h[(t + 1) & 1];
@@ -176,7 +210,7 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   }
   __syncthreads();
   float acc = 0.f;
-  if (row_ok && t > 0) acc = chain(P.w_hh + wrow * H, H);
+  if (t > 0) acc = project(P.w_hh + wrow * H, H);    // t is uniform
   if (row_ok && GATES == 3) acc += P.b_hh[wrow];
   sh_g[slot][bl] = acc;
   sh_x[slot][bl] = xp;
