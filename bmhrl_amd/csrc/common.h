@@ -67,9 +67,21 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   return (hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }
+// Dropout decisions need far less than the 64-bit mixer above (three 64-bit multiplies per element, in every GEMM / cast /
+// attention epilogue of the training step): a 32-bit finaliser (two rounds of xorshift-multiply, the "lowbias32" constants)
+// over (seed, element id).  Forward and backward call the same function, so the mask is reproduced from the element id.
+__device__ __forceinline__ uint32_t dropout_bits(uint64_t seed, uint64_t idx) {
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  x ^= ((uint32_t)(idx >> 32) + (uint32_t)(seed >> 32)) * 0x85EBCA77u;
+  x ^= x >> 16; x *= 0x21F0AAADu;
+  x ^= x >> 15; x *= 0x735A2D97u;
+  x ^= x >> 15;
+  return x;
+}
 // keep-scale of inverted dropout: 0 if dropped, 1/(1-p) if kept
 __device__ __forceinline__ float dropout_scale(float p, uint64_t seed, uint64_t idx) {
-  return uniform01(seed, idx) < p ? 0.f : 1.0f / (1.0f - p);
+  const uint32_t thr = (uint32_t)fminf(p * 4294967296.f, 4294967040.f);
+  return dropout_bits(seed, idx) < thr ? 0.f : 1.0f / (1.0f - p);
 }
 
 __device__ __forceinline__ bf16x8 zero_bf16x8() {

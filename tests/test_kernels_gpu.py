@@ -220,6 +220,30 @@ def test_attention_fwd_output_dropout(dev):
     assert float((d1[kept] - base[kept] / 0.75).abs().max()) < 2e-2 * float(base.abs().max()) / 0.75
 
 
+def test_dropout_mask_statistics(dev):
+    """the counter-based dropout bits: keep rate, no correlation between neighbouring elements, rows, or seeds"""
+    from bmhrl_amd import ops
+    rows, cols = 2048, 1024
+    x = torch.ones(rows, cols, device=dev)
+    masks = []
+    for p, seed in ((0.1, 1), (0.1, 2), (0.5, 1)):
+        y = ops.bf16_zeros(rows, cols, dev)
+        ops.cast_bf16(x, cols, y, cols, rows, cols, dropout_p=p, seed=seed)
+        m = (y.float() != 0)
+        assert abs(m.float().mean().item() - (1 - p)) < 2e-3
+        assert float((y.float()[m] - 1 / (1 - p)).abs().max()) < 1e-2
+        masks.append(m.float())
+    a, b, c = masks
+    def corr(u, v):
+        u = u - u.mean(); v = v - v.mean()
+        return float((u * v).mean() / (u.std() * v.std()))
+    assert abs(corr(a, b)) < 5e-3                                  # different seeds
+    assert abs(corr(a[:, 1:], a[:, :-1])) < 5e-3                   # neighbouring columns
+    assert abs(corr(a[1:], a[:-1])) < 5e-3                         # neighbouring rows
+    assert abs(corr(a[:, ::2], a[:, 1::2])) < 5e-3
+    assert float((a.mean(0) - 0.9).abs().max()) < 0.04 and float((a.mean(1) - 0.9).abs().max()) < 0.05   # no dead rows / columns
+
+
 def test_softmax_rows_and_delta(dev):
     from bmhrl_amd import ops
     g = torch.Generator().manual_seed(3)
