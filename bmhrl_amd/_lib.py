@@ -20,7 +20,7 @@ class RnnLayer(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
                 ("in_seq", C.c_void_p), ("in_ld", C.c_int64), ("in_dim", C.c_int32), ("gates", C.c_int32),
                 ("seq_out", C.c_void_p), ("h", C.c_void_p * 2), ("c", C.c_void_p * 2),
-                ("arelu_alpha", C.c_void_p), ("arelu_beta", C.c_void_p)]
+                ("arelu_alpha", C.c_void_p), ("arelu_beta", C.c_void_p), ("xproj", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -73,7 +73,7 @@ PROTOTYPES = {
     "bmhrl_reinforce_bwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_gemm_f32": [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, ptr],
     "bmhrl_rnn_step": [i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr],
-    "bmhrl_rnn_wavefront": [ptr, i32, i32, i32, i32, ptr],
+    "bmhrl_rnn_wavefront": [ptr, i32, i32, i32, i32, i32, ptr],
     "bmhrl_critic_head": [ptr, ptr, ptr, f32, ptr, ptr, i64, i32, ptr],
     "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
 }

@@ -128,13 +128,17 @@ __global__ __launch_bounds__(256) void rnn_step_kernel(const float* __restrict__
 constexpr int MAX_RNN_LAYERS = 8;
 struct RnnTable { bmhrl_rnn_layer l[MAX_RNN_LAYERS]; };
 
-__global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n_layers, int B, int L, int H, int s) {
+// `T` (chunk): layer l trails layer l - 1 by T time steps (cell (l, t) runs in launch t + T * l), so that at t % T == 0 the
+// inputs of T steps are ready and W_ih is read ONCE for them (projections kept in P.xproj); the recurrent half of a cell
+// still streams W_hh every step.  T = 1 is the plain diagonal.  Weight bytes per step of the whole stack:
+// 30 * 34.5 MB (W_hh) + 30 / T * 31.7 MB (W_ih).
+__global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n_layers, int B, int L, int H, int s, int T) {
   // x_t / h_{t-1} of the 16 batch rows go through LDS (every gate row of the block needs them); the weight rows do not:
   // a row belongs to one gate-row slot, its 16 batch lanes read the same 16 bytes (one broadcast fetch), nothing is reused,
   // so staging them would only add a pass and keep the block count per CU at one.
   __shared__ __attribute__((aligned(16))) float sh_h[16][MAXH + 4];
   __shared__ float sh_g[16][17], sh_x[16][17];
-  const int layer = blockIdx.z, t = s - layer;
+  const int layer = blockIdx.z, t = s - T * layer;
   if (t < 0 || t >= L) return;                      // uniform for the block
   const bmhrl_rnn_layer& P = tab.l[layer];
   const int GATES = P.gates;
@@ -149,15 +153,17 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   // once: one memory latency per row instead of a chain of them), accumulates its slice against all 16 batch rows
   // (x from LDS) and the 16 x 16 partial sums are reduce-scattered with 15 shuffles so that lane j ends with batch row j.
   // (fixed summation order; it differs from a k-ascending chain by fp32 rounding only)
-  auto project = [&](const float* __restrict__ w, const int K) {
-    constexpr int NP = (MAXH / 4 + 15) / 16;            // pieces per lane (10)
+  constexpr int NP = (MAXH / 4 + 15) / 16;              // 16-byte pieces of a weight row per lane (10)
+  auto load_row = [&](const float* __restrict__ w, const int K, f32x4 (&wv)[NP]) {
     const int nf = K / 4;
-    f32x4 wv[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int f = bl + 16 * i;
       wv[i] = f < nf ? *reinterpret_cast<const f32x4*>(w + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  auto apply_row = [&](const f32x4 (&wv)[NP], const int K) {      // -> sum_k w[k] * sh_h[b = bl][k]
+    const int nf = K / 4;
     float acc[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) acc[b] = 0.f;
@@ -187,19 +193,31 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
     }
     return acc[0];
   };
-  // pass 1: x_t (16 batch rows)
+  // pass 1: input projection of this cell -- or, with T > 1 and t % T == 0, of the next T cells of the layer
   const int K = P.in_dim;
-  for (int i = tid; i < 16 * (K / 4); i += 256) {
-    const int r = i / (K / 4), c4 = (i % (K / 4)) * 4;
-    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-    if (b0 + r < B) xv = *reinterpret_cast<const f32x4*>(P.in_seq + ((long)(b0 + r) * L + t) * P.in_ld + c4);
-    *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = xv;
-  }
-  __syncthreads();
+  const bool b_ok = b0 + bl < B;
+  const float bias_x = row_ok ? P.b_ih[wrow] + (GATES == 4 ? P.b_hh[wrow] : 0.f) : 0.f;
   float xp = 0.f;
-  xp = project(P.w_ih + wrow * K, K);               // (every lane takes part in the shuffles)
-  if (row_ok) xp += P.b_ih[wrow] + (GATES == 4 ? P.b_hh[wrow] : 0.f);
-  __syncthreads();
+  if (T == 1 || t % T == 0) {
+    f32x4 wv[NP];
+    load_row(P.w_ih + wrow * K, K, wv);
+    const int nt = T == 1 ? 1 : min(T, L - t);
+    for (int tt = 0; tt < nt; ++tt) {
+      for (int i = tid; i < 16 * (K / 4); i += 256) {
+        const int r = i / (K / 4), c4 = (i % (K / 4)) * 4;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (b0 + r < B) xv = *reinterpret_cast<const f32x4*>(P.in_seq + ((long)(b0 + r) * L + t + tt) * P.in_ld + c4);
+        *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = xv;
+      }
+      __syncthreads();
+      const float v = apply_row(wv, K) + bias_x;        // (every lane takes part in the shuffles)
+      if (tt == 0) xp = v;
+      else if (row_ok && b_ok) P.xproj[((long)(b0 + bl) * L + t + tt) * (GATES * H) + wrow] = v;
+      __syncthreads();
+    }
+  } else if (row_ok && b_ok) {
+    xp = P.xproj[((long)(b0 + bl) * L + t) * (GATES * H) + wrow];     // stored by this thread at the chunk's first step
+  }
   // pass 2: h_{t-1}
   const float* h_prev = P.h[(t + 1) & 1];
   for (int i = tid; i < 16 * (H / 4); i += 256) {
@@ -210,7 +228,11 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   }
   __syncthreads();
   float acc = 0.f;
-  if (t > 0) acc = project(P.w_hh + wrow * H, H);    // t is uniform
+  if (t > 0) {                                         // t is uniform
+    f32x4 wv[NP];
+    load_row(P.w_hh + wrow * H, H, wv);
+    acc = apply_row(wv, H);
+  }
   if (row_ok && GATES == 3) acc += P.b_hh[wrow];
   sh_g[slot][bl] = acc;
   sh_x[slot][bl] = xp;
@@ -286,21 +308,23 @@ extern "C" int bmhrl_rnn_step(int32_t gates, const float* xproj, const float* wh
 }
 
 extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_layers, int32_t B, int32_t L, int32_t H,
-                                   bmhrl_stream_t stream) {
+                                   int32_t chunk, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(layers && n_layers > 0 && n_layers <= MAX_RNN_LAYERS && B > 0 && L > 0 && H > 0 && H <= MAXH && H % 4 == 0);
+  BMHRL_CHECK_ARG(chunk >= 1 && chunk <= 16);
   RnnTable tab;
   for (int i = 0; i < n_layers; ++i) {
     const bmhrl_rnn_layer& p = layers[i];
     BMHRL_CHECK_ARG((p.gates == 3 || p.gates == 4) && p.w_ih && p.w_hh && p.b_ih && p.b_hh && p.in_seq && p.seq_out && p.h[0] && p.h[1]);
     BMHRL_CHECK_ARG(p.in_dim > 0 && p.in_dim <= MAXH && p.in_dim % 4 == 0 && p.in_ld % 4 == 0 && p.in_ld >= p.in_dim);
     BMHRL_CHECK_ARG(p.gates == 3 || (p.c[0] && p.c[1]));
+    BMHRL_CHECK_ARG(chunk == 1 || p.xproj != nullptr);
     BMHRL_CHECK_ARG((p.arelu_alpha == nullptr) == (p.arelu_beta == nullptr));
     BMHRL_CHECK_ARG((((uintptr_t)p.w_ih | (uintptr_t)p.w_hh | (uintptr_t)p.in_seq | (uintptr_t)p.h[0] | (uintptr_t)p.h[1]) & 15) == 0);
     tab.l[i] = p;
   }
   dim3 grid((unsigned)((H + UB - 1) / UB), (unsigned)((B + 15) / 16), (unsigned)n_layers), block(256);
-  for (int s = 0; s < L + n_layers - 1; ++s)
-    hipLaunchKernelGGL(rnn_wave_kernel, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s);
+  for (int s = 0; s < L + chunk * (n_layers - 1); ++s)
+    hipLaunchKernelGGL(rnn_wave_kernel, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
   return hip_status(hipGetLastError());
 }
 

@@ -224,6 +224,7 @@ class SegmentCritic(nn.Module):
             return self.lin(self.relu2(h))
 
     wavefront = True       # False: one GEMM + L step launches per layer (the first native form; kept for A/B and tests)
+    wave_chunk = 3         # time steps a layer trails the one below: W_ih is read once per chunk (ops.rnn_wavefront)
 
     def score_and_labels(self, emb, threshold):
         """HIP path, fp32.  Returns (score (B, L, 1), labels (B, L) int32 = sigmoid(score) > threshold).
@@ -248,9 +249,10 @@ class SegmentCritic(nn.Module):
                         in_seq=x, in_ld=x.shape[1], in_dim=x.shape[1], gates=gates, seq_out=seq,
                         h=[torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)],
                         c=[torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)] if gates == 4 else None,
-                        arelu_alpha=act.alpha if last else None, arelu_beta=act.beta if last else None))
+                        arelu_alpha=act.alpha if last else None, arelu_beta=act.beta if last else None,
+                        xproj=torch.empty(rows, gates * H, device=dev) if self.wave_chunk > 1 else None))
                     x = seq
-            ops.rnn_wavefront(layers, B, L, H)
+            ops.rnn_wavefront(layers, B, L, H, chunk=self.wave_chunk)
         else:
             hb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
             cb = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]

@@ -240,9 +240,9 @@ def rnn_step(gates, xproj, whh, bhh, h_prev, c_prev, h_out, c_out, seq_out, ar_a
                                           stream()), "bmhrl_rnn_step")
 
 
-def rnn_wavefront(layers, B, L, H):
-    """layers: list of dicts with the fields of bmhrl_rnn_layer (tensors / None); runs the whole stack, L + len(layers) - 1
-    launches"""
+def rnn_wavefront(layers, B, L, H, chunk=1):
+    """layers: list of dicts with the fields of bmhrl_rnn_layer (tensors / None); runs the whole stack in
+    L + chunk * (len(layers) - 1) launches"""
     arr = (_lib.RnnLayer * len(layers))()
     for d, a in zip(layers, arr):
         a.w_ih, a.w_hh, a.b_ih, a.b_hh = d["w_ih"].data_ptr(), d["w_hh"].data_ptr(), d["b_ih"].data_ptr(), d["b_hh"].data_ptr()
@@ -251,7 +251,9 @@ def rnn_wavefront(layers, B, L, H):
         a.h[0], a.h[1] = d["h"][0].data_ptr(), d["h"][1].data_ptr()
         a.c[0], a.c[1] = (d["c"][0].data_ptr(), d["c"][1].data_ptr()) if d.get("c") is not None else (None, None)
         a.arelu_alpha, a.arelu_beta = _p(d.get("arelu_alpha")), _p(d.get("arelu_beta"))
-    _lib.check(_lib.load().bmhrl_rnn_wavefront(C.cast(arr, C.c_void_p), len(layers), B, L, H, stream()), "bmhrl_rnn_wavefront")
+        a.xproj = _p(d.get("xproj"))
+    _lib.check(_lib.load().bmhrl_rnn_wavefront(C.cast(arr, C.c_void_p), len(layers), B, L, H, chunk, stream()),
+               "bmhrl_rnn_wavefront")
 
 
 def critic_head(x, w, b, threshold, score, labels, rows, H):

@@ -228,19 +228,21 @@ int bmhrl_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, con
 int bmhrl_rnn_step(int32_t gates, const float* xproj, const float* whh, const float* bhh, const float* h_prev,
                    const float* c_prev, float* h_out, float* c_out, float* seq_out, const float* arelu_alpha,
                    const float* arelu_beta, int32_t B, int32_t L, int32_t H, int32_t t, bmhrl_stream_t stream);
-/* The whole recurrent stack as a wavefront over (layer, time): cell (l, t) runs in launch l + t, so the stack takes
+/* The whole recurrent stack as a wavefront over (layer, time): cell (l, t) runs in launch l + t (chunk = 1), so the stack takes
  * L + n_layers - 1 launches (all cells of a diagonal in one grid) instead of n_layers * (1 + L).  Layer l reads
  * in_seq (B, L, in_ld) -- the embeddings for l = 0, seq_out of layer l - 1 otherwise -- and writes seq_out (B, L, H)
  * (through AReLU when arelu_alpha / arelu_beta are given: the last layer of the LSTM and of the GRU stack,
- * model/bm_hrl_agent.py:209-213); h / c are two (B, H) state buffers each (c unused for the GRU).  fp32 throughout,
- * same arithmetic order as bmhrl_gemm_f32 + bmhrl_rnn_step. */
+ * model/bm_hrl_agent.py:209-213); h / c are two (B, H) state buffers each (c unused for the GRU).  fp32 throughout.
+ * With chunk = T > 1 cell (l, t) runs in launch t + T*l (L + T*(n_layers-1) launches). */
 typedef struct bmhrl_rnn_layer {
   const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;   /* nn.LSTM / nn.GRU parameter layout */
   const float* in_seq; int64_t in_ld; int32_t in_dim; int32_t gates;            /* gates: 4 = LSTM (i,f,g,o), 3 = GRU (r,z,n) */
   float* seq_out; float* h[2]; float* c[2];
   const float* arelu_alpha; const float* arelu_beta;
+  float* xproj;                                           /* (B, L, gates*H) scratch, needed when chunk > 1 */
 } bmhrl_rnn_layer;
 int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_layers, int32_t B, int32_t L, int32_t H,
+                        int32_t chunk /* time steps a layer trails the one below: W_ih is read once per chunk */,
                         bmhrl_stream_t stream);
 int bmhrl_critic_head(const float* x, const float* w, const float* b, float threshold, float* score, int32_t* labels,
                       int64_t rows, int32_t H, bmhrl_stream_t stream);

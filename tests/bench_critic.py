@@ -6,8 +6,9 @@ from bmhrl_amd.model.bm_hrl_agent import SegmentCritic
 dev = torch.device("cuda:0")
 c = SegmentCritic(syn.default_cfg()); c.load_state_dict(syn.synthetic_critic_state(300, seed=1)); c = c.to(dev)
 emb = (torch.randn(16, 30, 300) * 17.3).to(dev)
-for wf in (True, False, True, False):
+for wf, ch in ((True, 1), (True, 2), (True, 3), (True, 5), (False, 1), (True, 3)):
     c.wavefront = wf
+    c.wave_chunk = ch
     c.score_and_labels(emb, 0.25); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -18,4 +19,4 @@ for wf in (True, False, True, False):
     e0.record()
     for _ in range(5): g.replay()
     e1.record(); torch.cuda.synchronize()
-    print(f"critic wavefront={wf}: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us")
+    print(f"critic wavefront={wf} chunk={ch}: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us")

@@ -53,8 +53,9 @@ def test_critic_full_width_vs_oracle(wavefront):
     assert torch.equal(labels.cpu()[ok], O.segment_labels(ref, 0.25)[ok])
 
 
+@pytest.mark.parametrize("chunk", [1, 2, 3, 5, 16])
 @pytest.mark.parametrize("B,L", [(16, 30), (3, 7), (33, 2), (1, 1)])
-def test_wavefront_equals_layer_by_layer(B, L):
+def test_wavefront_equals_layer_by_layer(B, L, chunk):
     """the (layer, time) wavefront with the fused input projection against the GEMM + step form (summation order differs by
     fp32 rounding only); batch > 16 (two batch blocks), single step, single row"""
     if not torch.cuda.is_available():
@@ -63,6 +64,7 @@ def test_wavefront_equals_layer_by_layer(B, L):
     c = _critic(syn.default_cfg(), dev)
     emb = (torch.randn(B, L, 300, generator=torch.Generator().manual_seed(B * 100 + L)) * 17.3).to(dev)
     c.wavefront = True
+    c.wave_chunk = chunk                                 # layers trail each other by `chunk` steps; W_ih once per chunk
     s1, l1 = c.score_and_labels(emb, 0.25)
     c.wavefront = False
     s0, l0 = c.score_and_labels(emb, 0.25)
