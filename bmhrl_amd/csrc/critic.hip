@@ -7,6 +7,7 @@
 // gate rows of W_hh, 16 x H floats) and all batch rows; h_{t-1} and the weight rows are staged in LDS (16-byte
 // reads, the weight row is a broadcast across the 16 batch lanes); the gate pre-activations are exchanged through
 // LDS and 4 x 16 threads apply the cell equations.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/bmhrl_hip.h"
 
@@ -132,41 +133,52 @@ struct RnnTable { bmhrl_rnn_layer l[MAX_RNN_LAYERS]; };
 // inputs of T steps are ready and W_ih is read ONCE for them (projections kept in P.xproj); the recurrent half of a cell
 // still streams W_hh every step.  T = 1 is the plain diagonal.  Weight bytes per step of the whole stack:
 // 30 * 34.5 MB (W_hh) + 30 / T * 31.7 MB (W_ih).
+template <int SPT>
 __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n_layers, int B, int L, int H, int s, int T) {
-  // x_t / h_{t-1} of the 16 batch rows go through LDS (every gate row of the block needs them); the weight rows do not:
-  // a row belongs to one gate-row slot, its 16 batch lanes read the same 16 bytes (one broadcast fetch), nothing is reused,
-  // so staging them would only add a pass and keep the block count per CU at one.
+  // A block owns UBW = 4 * SPT hidden units (all their gate rows: NS = 16 * SPT row slots) and 16 batch rows.  x_t / h_{t-1}
+  // of the batch rows go through LDS; the weight rows do not (a row belongs to one slot, nothing in it is reused).  A
+  // thread serves SPT slots, so every x value read from LDS feeds SPT weight rows (LDS reads, not FMAs, bound the cell).
+  constexpr int UBW = UB * SPT, NS = 16 * SPT;
   __shared__ __attribute__((aligned(16))) float sh_h[16][MAXH + 4];
-  __shared__ float sh_g[16][17], sh_x[16][17];
+  __shared__ float sh_g[NS][17], sh_x[NS][17];
   const int layer = blockIdx.z, t = s - T * layer;
   if (t < 0 || t >= L) return;                      // uniform for the block
   const bmhrl_rnn_layer& P = tab.l[layer];
   const int GATES = P.gates;
   const int tid = threadIdx.x;
-  const int u0 = blockIdx.x * UB, b0 = blockIdx.y * 16;
-  const int slot = tid >> 4, bl = tid & 15;
-  const int gate = slot / UB, unit = u0 + slot % UB;
-  const bool row_ok = gate < GATES && unit < H;
-  const long wrow = (long)(row_ok ? gate * H + unit : 0);
-  // y[b] = sum_k w[k] * sh_h[b][k] for the 16 batch rows of the block.  The 16 lanes of a gate-row slot split the row:
-  // lane j owns the 16-byte pieces j, j + 16, ... (coalesced 256-byte reads, all of a lane's <= 10 pieces requested at
-  // once: one memory latency per row instead of a chain of them), accumulates its slice against all 16 batch rows
-  // (x from LDS) and the 16 x 16 partial sums are reduce-scattered with 15 shuffles so that lane j ends with batch row j.
-  // (fixed summation order; it differs from a k-ascending chain by fp32 rounding only)
+  const int u0 = blockIdx.x * UBW, b0 = blockIdx.y * 16;
+  const int sg = tid >> 4, bl = tid & 15;
+  bool row_ok[SPT];
+  long wrow[SPT];
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    const int slot = sg + 16 * q, gate = slot / UBW, unit = u0 + slot % UBW;
+    row_ok[q] = gate < GATES && unit < H;
+    wrow[q] = row_ok[q] ? (long)gate * H + unit : 0;
+  }
   constexpr int NP = (MAXH / 4 + 15) / 16;              // 16-byte pieces of a weight row per lane (10)
-  auto load_row = [&](const float* __restrict__ w, const int K, f32x4 (&wv)[NP]) {
+  // The 16 lanes of a slot split its weight row: lane j owns the pieces j, j + 16, ... (coalesced 256-byte reads, all of a
+  // lane's pieces requested at once: one memory latency per row, not a chain of them) ...
+  auto load_rows = [&](const float* __restrict__ w, const int K, f32x4 (&wv)[SPT][NP]) {
     const int nf = K / 4;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int f = bl + 16 * i;
-      wv[i] = f < nf ? *reinterpret_cast<const f32x4*>(w + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int q = 0; q < SPT; ++q)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int f = bl + 16 * i;
+        wv[q][i] = f < nf ? *reinterpret_cast<const f32x4*>(w + wrow[q] * K + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
   };
-  auto apply_row = [&](const f32x4 (&wv)[NP], const int K) {      // -> sum_k w[k] * sh_h[b = bl][k]
+  // ... accumulates its slice against all 16 batch rows (x from LDS), and the 16 x 16 partial sums of a slot are
+  // reduce-scattered with 15 shuffles so that lane j ends with batch row j: out[q] = sum_k w_q[k] * sh_h[bl][k]
+  // (fixed summation order; it differs from a k-ascending chain by fp32 rounding only)
+  auto apply_rows = [&](const f32x4 (&wv)[SPT][NP], const int K, float (&out)[SPT]) {
     const int nf = K / 4;
-    float acc[16];
+    float acc[SPT][16];
 #pragma unroll
-    for (int b = 0; b < 16; ++b) acc[b] = 0.f;
+    for (int q = 0; q < SPT; ++q)
+#pragma unroll
+      for (int b = 0; b < 16; ++b) acc[q][b] = 0.f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int f = bl + 16 * i;
@@ -174,86 +186,101 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
           const f32x4 xv = *reinterpret_cast<const f32x4*>(&sh_h[b][4 * f]);
-          acc[b] = fmaf(wv[i][0], xv[0], acc[b]); acc[b] = fmaf(wv[i][1], xv[1], acc[b]);
-          acc[b] = fmaf(wv[i][2], xv[2], acc[b]); acc[b] = fmaf(wv[i][3], xv[3], acc[b]);
+#pragma unroll
+          for (int q = 0; q < SPT; ++q) {
+            acc[q][b] = fmaf(wv[q][i][0], xv[0], acc[q][b]); acc[q][b] = fmaf(wv[q][i][1], xv[1], acc[q][b]);
+            acc[q][b] = fmaf(wv[q][i][2], xv[2], acc[q][b]); acc[q][b] = fmaf(wv[q][i][3], xv[3], acc[q][b]);
+          }
         }
       }
     }
-    // reduce-scatter over the 16 lanes of the slot: after the step with mask m a lane keeps the batch rows whose bit m
-    // equals its own
 #pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) {
-      const bool hi = (bl & m) != 0;
+    for (int q = 0; q < SPT; ++q) {
 #pragma unroll
-      for (int b = 0; b < m; ++b) {
-        const float send = hi ? acc[b] : acc[b + m];
-        const float keep = hi ? acc[b + m] : acc[b];
-        acc[b] = keep + __shfl_xor(send, m, 64);
+      for (int m = 8; m >= 1; m >>= 1) {     // after the step with mask m a lane keeps the batch rows whose bit m equals its own
+        const bool hi = (bl & m) != 0;
+#pragma unroll
+        for (int b = 0; b < m; ++b) {
+          const float send = hi ? acc[q][b] : acc[q][b + m];
+          const float keep = hi ? acc[q][b + m] : acc[q][b];
+          acc[q][b] = keep + __shfl_xor(send, m, 64);
+        }
       }
+      out[q] = acc[q][0];
     }
-    return acc[0];
+  };
+  auto stage = [&](const float* __restrict__ src, const long row_stride, const int K, const bool live) {
+    for (int i = tid; i < 16 * (K / 4); i += 256) {
+      const int r = i / (K / 4), c4 = (i % (K / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (live && b0 + r < B) v = *reinterpret_cast<const f32x4*>(src + (long)(b0 + r) * row_stride + c4);
+      *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = v;
+    }
   };
   // pass 1: input projection of this cell -- or, with T > 1 and t % T == 0, of the next T cells of the layer
   const int K = P.in_dim;
   const bool b_ok = b0 + bl < B;
-  const float bias_x = row_ok ? P.b_ih[wrow] + (GATES == 4 ? P.b_hh[wrow] : 0.f) : 0.f;
-  float xp = 0.f;
+  float bias_x[SPT], xp[SPT];
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    bias_x[q] = row_ok[q] ? P.b_ih[wrow[q]] + (GATES == 4 ? P.b_hh[wrow[q]] : 0.f) : 0.f;
+    xp[q] = 0.f;
+  }
   if (T == 1 || t % T == 0) {
-    f32x4 wv[NP];
-    load_row(P.w_ih + wrow * K, K, wv);
+    f32x4 wv[SPT][NP];
+    load_rows(P.w_ih, K, wv);
     const int nt = T == 1 ? 1 : min(T, L - t);
     for (int tt = 0; tt < nt; ++tt) {
-      for (int i = tid; i < 16 * (K / 4); i += 256) {
-        const int r = i / (K / 4), c4 = (i % (K / 4)) * 4;
-        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-        if (b0 + r < B) xv = *reinterpret_cast<const f32x4*>(P.in_seq + ((long)(b0 + r) * L + t + tt) * P.in_ld + c4);
-        *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = xv;
+      stage(P.in_seq + (long)(t + tt) * P.in_ld, (long)L * P.in_ld, K, true);
+      __syncthreads();
+      float v[SPT];
+      apply_rows(wv, K, v);                             // (every lane takes part in the shuffles)
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) {
+        if (tt == 0) xp[q] = v[q] + bias_x[q];
+        else if (row_ok[q] && b_ok) P.xproj[((long)(b0 + bl) * L + t + tt) * (GATES * H) + wrow[q]] = v[q] + bias_x[q];
       }
       __syncthreads();
-      const float v = apply_row(wv, K) + bias_x;        // (every lane takes part in the shuffles)
-      if (tt == 0) xp = v;
-      else if (row_ok && b_ok) P.xproj[((long)(b0 + bl) * L + t + tt) * (GATES * H) + wrow] = v;
-      __syncthreads();
     }
-  } else if (row_ok && b_ok) {
-    xp = P.xproj[((long)(b0 + bl) * L + t) * (GATES * H) + wrow];     // stored by this thread at the chunk's first step
+  } else if (b_ok) {
+#pragma unroll
+    for (int q = 0; q < SPT; ++q)                       // stored by this thread at the chunk's first step
+      if (row_ok[q]) xp[q] = P.xproj[((long)(b0 + bl) * L + t) * (GATES * H) + wrow[q]];
   }
   // pass 2: h_{t-1}
-  const float* h_prev = P.h[(t + 1) & 1];
-  for (int i = tid; i < 16 * (H / 4); i += 256) {
-    const int r = i / (H / 4), c4 = (i % (H / 4)) * 4;
-    f32x4 hv = {0.f, 0.f, 0.f, 0.f};
-    if (b0 + r < B && t > 0) hv = *reinterpret_cast<const f32x4*>(h_prev + (long)(b0 + r) * H + c4);
-    *reinterpret_cast<f32x4*>(&sh_h[r][c4]) = hv;
-  }
+  stage(P.h[(t + 1) & 1], H, H, t > 0);
   __syncthreads();
-  float acc = 0.f;
+  float acc[SPT];
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) acc[q] = 0.f;
   if (t > 0) {                                         // t is uniform
-    f32x4 wv[NP];
-    load_row(P.w_hh + wrow * H, H, wv);
-    acc = apply_row(wv, H);
+    f32x4 wv[SPT][NP];
+    load_rows(P.w_hh, H, wv);
+    apply_rows(wv, H, acc);
   }
-  if (row_ok && GATES == 3) acc += P.b_hh[wrow];
-  sh_g[slot][bl] = acc;
-  sh_x[slot][bl] = xp;
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    if (row_ok[q] && GATES == 3) acc[q] += P.b_hh[wrow[q]];
+    sh_g[sg + 16 * q][bl] = acc[q];
+    sh_x[sg + 16 * q][bl] = xp[q];
+  }
   __syncthreads();
-  if (tid < UB * 16) {
-    const int u = u0 + (tid >> 4), b = b0 + bl;
+  if (tid < UBW * 16) {
+    const int ul = tid >> 4, u = u0 + ul, b = b0 + bl;
     if (u < H && b < B) {
-      const int ul = tid >> 4;
       float hn;
       if (GATES == 4) {
         const float gi = sigmoidf_(sh_x[ul][bl] + sh_g[ul][bl]);
-        const float gf = sigmoidf_(sh_x[UB + ul][bl] + sh_g[UB + ul][bl]);
-        const float gg = tanhf(sh_x[2 * UB + ul][bl] + sh_g[2 * UB + ul][bl]);
-        const float go = sigmoidf_(sh_x[3 * UB + ul][bl] + sh_g[3 * UB + ul][bl]);
+        const float gf = sigmoidf_(sh_x[UBW + ul][bl] + sh_g[UBW + ul][bl]);
+        const float gg = tanhf(sh_x[2 * UBW + ul][bl] + sh_g[2 * UBW + ul][bl]);
+        const float go = sigmoidf_(sh_x[3 * UBW + ul][bl] + sh_g[3 * UBW + ul][bl]);
         const float c = gf * (t > 0 ? P.c[(t + 1) & 1][(long)b * H + u] : 0.f) + gi * gg;
         P.c[t & 1][(long)b * H + u] = c;
         hn = go * tanhf(c);
       } else {
         const float r = sigmoidf_(sh_x[ul][bl] + sh_g[ul][bl]);
-        const float z = sigmoidf_(sh_x[UB + ul][bl] + sh_g[UB + ul][bl]);
-        const float n = tanhf(sh_x[2 * UB + ul][bl] + r * sh_g[2 * UB + ul][bl]);
+        const float z = sigmoidf_(sh_x[UBW + ul][bl] + sh_g[UBW + ul][bl]);
+        const float n = tanhf(sh_x[2 * UBW + ul][bl] + r * sh_g[2 * UBW + ul][bl]);
         hn = (1.f - z) * n + z * (t > 0 ? sh_h[bl][u] : 0.f);
       }
       P.h[t & 1][(long)b * H + u] = hn;
@@ -322,9 +349,13 @@ extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_laye
     BMHRL_CHECK_ARG((((uintptr_t)p.w_ih | (uintptr_t)p.w_hh | (uintptr_t)p.in_seq | (uintptr_t)p.h[0] | (uintptr_t)p.h[1]) & 15) == 0);
     tab.l[i] = p;
   }
-  dim3 grid((unsigned)((H + UB - 1) / UB), (unsigned)((B + 15) / 16), (unsigned)n_layers), block(256);
-  for (int s = 0; s < L + chunk * (n_layers - 1); ++s)
-    hipLaunchKernelGGL(rnn_wave_kernel, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
+  static const int spt = getenv("BMHRL_RNN_SPT") ? atoi(getenv("BMHRL_RNN_SPT")) : 2;     // gate rows per thread (tuning aid: 1)
+  const int ubw = UB * (spt == 1 ? 1 : 2);
+  dim3 grid((unsigned)((H + ubw - 1) / ubw), (unsigned)((B + 15) / 16), (unsigned)n_layers), block(256);
+  for (int s = 0; s < L + chunk * (n_layers - 1); ++s) {
+    if (spt == 1) hipLaunchKernelGGL(rnn_wave_kernel<1>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
+    else hipLaunchKernelGGL(rnn_wave_kernel<2>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
+  }
   return hip_status(hipGetLastError());
 }
 
