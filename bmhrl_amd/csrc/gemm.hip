@@ -307,7 +307,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
     __syncthreads();
     const uint8_t* __restrict__ Mk = (prob && p.mask) ? p.mask + b1 * p.mask_sb1 : nullptr;     // key mask (mask_sm == 0)
-    auto finish = [&](const f32x16& av, const int mi, const int ni) {
+    // a lane's 16 accumulator rows are 4 groups of 4 consecutive rows: the row vectors come in as 16-byte LDS reads, once
+    // per 32-row tile (not once per element and output tile)
+    auto finish = [&](const f32x16& av, const int mi, const int ni, const f32x4 (&r1)[4], const f32x4 (&r2)[4]) {
       const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
       const bool keep = !Mk || n >= p.N || Mk[n] != 0;
       const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
@@ -318,19 +320,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         float v;
         if (prob) {
           const float x = keep ? av[r] * p.alpha : NEG_MASK;
-          v = __expf(x - sRV[row]) * sRV2[row];
+          v = __expf(x - r1[r >> 2][r & 3]) * r2[r >> 2][r & 3];
         } else {
-          v = (float)*q * (av[r] - sRV[row]) * p.alpha;
+          v = (float)*q * (av[r] - r1[r >> 2][r & 3]) * p.alpha;
         }
         *q = (bf16_t)v;
       }
     };
-    finish(acc[0][0], 0, 0);
-    if constexpr (TN > 1) finish(acc[0][1], 0, 1);
-    if constexpr (TM > 1) {
-      finish(acc[1][0], 1, 0);
-      if constexpr (TN > 1) finish(acc[1][1], 1, 1);
-    }
+    auto finish_rows = [&](const int mi) {
+      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+      f32x4 r1[4], r2[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        r1[g] = *reinterpret_cast<const f32x4*>(sRV + row0 + 8 * g);
+        r2[g] = *reinterpret_cast<const f32x4*>(sRV2 + row0 + 8 * g);
+      }
+      finish(acc[mi][0], mi, 0, r1, r2);
+      if constexpr (TN > 1) finish(acc[mi][1], mi, 1, r1, r2);
+    };
+    finish_rows(0);
+    if constexpr (TM > 1) finish_rows(1);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < G8; ++i) {
