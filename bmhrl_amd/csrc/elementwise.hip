@@ -663,6 +663,16 @@ extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const flo
   float* dg = dgamma ? dgamma : dbeta;
   float* db = dbeta ? dbeta : dgamma;
   const int nv = (D + 255) / 256;
+  // few blocks (the caption-side rows: 480 x 300 -> 120 blocks): the same-address atomics are short then, and cheaper
+  // than a second launch on the step's serial chain
+  static const long atomic_max = getenv("BMHRL_LN_ATOMIC_BLOCKS") ? atol(getenv("BMHRL_LN_ATOMIC_BLOCKS")) : 128;
+  if (blocks <= atomic_max) {
+#define LN_BWDA(NV_) hipLaunchKernelGGL((ln_bwd_vec_kernel<NV_, false>), gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
+                                        dx_add, dgamma, dbeta, (long)rows, D, rv, (float*)nullptr)
+    if (nv <= 1) LN_BWDA(1); else if (nv <= 2) LN_BWDA(2); else LN_BWDA(4);
+#undef LN_BWDA
+    return hip_status(hipGetLastError());
+  }
 #define LN_BWDP(NV_) hipLaunchKernelGGL((ln_bwd_vec_kernel<NV_, true>), gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
                                         dx_add, dg, db, (long)rows, D, rv, workspace)
   if (nv <= 1) LN_BWDP(1); else if (nv <= 2) LN_BWDP(2); else LN_BWDP(4);
