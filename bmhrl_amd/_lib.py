@@ -47,6 +47,7 @@ PROTOTYPES = {
     "bmhrl_attention_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, f32,
                             f32, u64, ptr, ptr],
     "bmhrl_attention_shared128_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, i32, f32, ptr],
+    "bmhrl_attention_config": [i32, i32],
     "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, ptr],
     "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],

@@ -7,12 +7,16 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbmhrl_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "critic.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "attention128.hip", "elementwise.hip", "loss.hip", "critic.hip"]
+HEADERS = ["common.h", "attention_fwd.h"]
 # attention.hip: the eight 16-register O^T accumulators are loop-carried vector PHIs; AMDGPUCodeGenPrepare would break
 # them into 128 scalar (VGPR) PHIs, i.e. 128 accumulator<->VGPR copies per key tile around the MFMAs.
 # gemm.hip: same for the MFMA tile accumulators of the main loop (1-3 % on the large shapes).
 _VECTOR_PHIS = ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]
-EXTRA_FLAGS = {"attention.hip": _VECTOR_PHIS, "gemm.hip": _VECTOR_PHIS}
+# attention128.hip (256 registers per wave, two waves per SIMD): MFMA results in arch VGPRs -- with no accumulator-register
+# operand in the file the compiler treats the 256 registers as one file (see the file's header).
+EXTRA_FLAGS = {"attention.hip": _VECTOR_PHIS, "gemm.hip": _VECTOR_PHIS,
+               "attention128.hip": _VECTOR_PHIS + ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc() -> str:
@@ -26,7 +30,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + ["common.h"]]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     deps.append(os.path.join(os.path.dirname(CSRC), "..", "include", "bmhrl_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -540,7 +540,7 @@ class MemAttnFn(torch.autograd.Function):
                  b_strides=(0, dk * w_k.shape[1]), C_bf16=Qp, ldcb=H * dmp, cb_strides=(0, dmp))
         m8, msb, msq = _mask_u8(mask)
         Cx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
-        flash = dm == 128 and L >= 128 and Sk <= 1024 and msq == 0
+        flash = dm == 128 and L >= 128 and msq == 0
         if flash:
             # many queries against the 128-wide (audio) rows: fused kernel, one key / value tile for all heads; the
             # probabilities are recomputed in backward from the softmax statistics

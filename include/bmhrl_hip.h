@@ -89,10 +89,14 @@ int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, 
  * X (B,Sk,128) serves every head as keys and values; Q_h K_h^T differs from Qp_h X^T only by a per-row constant, and
  * P_h V_h = context_h Wv_h^T + bv_h (model/multihead_attention.py:7-31 with K = X Wk^T + bk, V = X Wv^T + bv).
  * ctx (B,Sq,H,128) bf16, normalised, no dropout (it applies after the Wv projection).  mask: (B,Sk) bytes or NULL.
- * row_max / row_sum as bmhrl_attention_fwd.  Sk <= 1024. */
+ * row_max / row_sum as bmhrl_attention_fwd.  (Both attention entry points accept Sk up to 10 112.) */
 int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo,
                                   float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
                                   int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale, bmhrl_stream_t stream);
+
+/* Tuning aid: pin the (query blocks x key splits) shape of the attention workgroups -- head_dim 256 or 128; code = 10 * QW + KW
+ * (41: 4 x 1, 22: 2 x 2), 0 = automatic (the default).  Process-wide, not thread-safe; results do not depend on it. */
+int bmhrl_attention_config(int32_t head_dim, int32_t code);
 
 /* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
  * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */

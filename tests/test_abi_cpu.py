@@ -22,7 +22,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(_lib.PROTOTYPES) | {"bmhrl_hip_arch", "bmhrl_hip_abi_version", "bmhrl_layernorm_bwd_workspace"} == set(syms)
     assert lib.bmhrl_layernorm_bwd_workspace(4096, 1024) == 256 * 2 * 1024      # 4 rows per wave, 4 waves per block: 256 blocks
     assert lib.bmhrl_hip_arch() == b"gfx950"
-    assert lib.bmhrl_hip_abi_version() == 3
+    assert lib.bmhrl_hip_abi_version() == 4
 
 
 def test_ops_refuse_cpu_tensors():
