@@ -15,9 +15,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define WAVE 64
 #define NEG_MASK (-1e9f)  // reference: masked_fill(mask == False, -1e9), model/multihead_attention.py:22
 
-#define BMHRL_CHECK_ARG(cond) \
-  do {                        \
-    if (!(cond)) return -22;  \
+// argument checks of the C ABI: -22 (EINVAL); BMHRL_DEBUG_ARGS=1 in the environment names the failed condition on stderr
+#include <cstdio>
+#include <cstdlib>
+static inline void bmhrl_arg_fail(const char* cond, const char* file, int line) {
+  static const bool verbose = getenv("BMHRL_DEBUG_ARGS") != nullptr;
+  if (verbose) fprintf(stderr, "bmhrl_hip: invalid argument: (%s) is false at %s:%d\n", cond, file, line);
+}
+#define BMHRL_CHECK_ARG(cond)                      \
+  do {                                             \
+    if (!(cond)) {                                 \
+      bmhrl_arg_fail(#cond, __FILE__, __LINE__);   \
+      return -22;                                  \
+    }                                              \
   } while (0)
 
 static inline int hip_status(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }

@@ -195,6 +195,28 @@ __global__ void smooth_kl_bwd_kernel(const float* __restrict__ logp, long ld, co
   }
 }
 
+// d rowloss / d log(raw amplitude) of every row (0 where the clamp is active, on pad rows the reference zeroes, without a sampled
+// token): what the backward adds to column a of the row itself.  The manager branch of biased_kl() needs it per row: its
+// amplitude holds the PRODUCT of the sampled tokens' probabilities over a segment, so the same quantity also flows to the
+// other tokens of the segment (epoch_loops/captioning_bmrl_loops.py:299-317).
+__global__ void smooth_kl_amp_grad_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
+                                          const int64_t* __restrict__ btrg, const float* __restrict__ score,
+                                          const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
+                                          float* __restrict__ out, long rows, int V) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float* lp = logp + row * ld;
+  float raw = 0.f;
+  const RowTarget T = make_target(lp, trg, btrg, score, n_row, smoothing, pad, zero_pad_rows, row, rows, V, &raw);
+  float e = 0.f;
+  if (T.a >= 0 && !T.zero_row && raw >= 0.f && raw <= 1.f) {
+    float g = __logf(T.at(T.a)) + 1.f - lp[T.a];
+    if (T.t != T.pad) g -= __logf(T.at(T.t)) + 1.f - lp[T.t];
+    e = T.keep * g * raw;
+  }
+  out[row] = e;
+}
+
 __global__ void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp, long ld,
                                        bf16_t* __restrict__ gb, long ldg, int V) {
   __shared__ float red[16];
@@ -325,6 +347,15 @@ extern "C" int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t*
   hipLaunchKernelGGL(smooth_kl_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
                      score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, wrt_logits, (bf16_t*)dlogits_bf16,
                      (long)ldg, dlogits_f32, (long)rows, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_smooth_kl_amp_grad(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
+                                        const float* score, const float* n_row, float smoothing, int32_t pad_idx,
+                                        int32_t zero_pad_rows, float* out, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && trg && biased_trg && score && n_row && out && rows > 0 && V > 2);
+  hipLaunchKernelGGL(smooth_kl_amp_grad_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, S_(stream), logp, (long)ld,
+                     trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, out, (long)rows, V);
   return hip_status(hipGetLastError());
 }
 

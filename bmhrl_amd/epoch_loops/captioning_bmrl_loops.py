@@ -96,22 +96,38 @@ def sample_actions(prediction, greedy, seed):
 
 def biased_kl(train_worker, prediction, scorer, expected_scores, trg, trg_caption, mask, segments, device, biased_kldiv,
               stabilize, reward_fn=None, seed=None):
-    """Worker branch of the reference's biased_kl (:271-334).  Returns (row sums of the divergence (B*L, 1), [score],
-    [sampled], [amplitude])."""
-    if not train_worker:
-        raise NotImplementedError("the reference's manager branch raises before reaching the loss (:852-854)")
+    """The reference's biased_kl (:271-334), both branches.  Worker: a ~ Categorical(exp(prediction)), amplitude =
+    clamp(score * p(a) * n_tokens_row, 0, 1).  Manager (:299-317): a = arg-max, score *= segments, amplitude =
+    clamp(score * prod_{segment} p(a) * n_segments_row, 0, 1) and the expected scores are summed per segment, with the
+    row-transition quirks of the reference's Python loop (rl_glue.manager_segments).  Returns (row sums of the divergence
+    (B*L, 1), [score], [sampled], [amplitude]).  Rewards: `reward_fn(sampled, captions) -> (B, L)` when given (BASELINE
+    config 3: synthetic), else the scorer's delta_*_worker / delta_*_manager."""
+    from .. import rl_glue
     seed = random.getrandbits(62) if seed is None else seed
-    sampled, _ = sample_actions(prediction, greedy=False, seed=seed)
+    sampled, _ = sample_actions(prediction, greedy=not train_worker, seed=seed)
     if reward_fn is not None:
         score = reward_fn(sampled, trg_caption)
+    elif train_worker:
+        score = scorer.delta_cider_worker(sampled, trg_caption)[0] if getattr(scorer, "type", "") == "CIDER" else \
+            (scorer.delta_bleu_worker(sampled, trg_caption)[0] if getattr(scorer, "type", "") == "BLEU" else
+             scorer.delta_meteor_worker(sampled, trg_caption, mask)[0])
     else:
-        score = scorer.delta_cider_worker(sampled, trg_caption, mask)[0] if hasattr(scorer, "delta_cider_worker") else \
-            scorer.delta_meteor_worker(sampled, trg_caption, mask)[0]
+        fn = {"CIDER": "delta_cider_manager", "BLEU": "delta_bleu_manager"}.get(getattr(scorer, "type", ""), "delta_meteor_manager")
+        score = getattr(scorer, fn)(sampled, trg_caption, mask, segments)[0]
     score = score.to(device).float()
+    n_row = get_norm_reward_factor(train_worker, mask, segments).float()
+    if train_worker:
+        if stabilize:
+            score = (score - expected_scores) * mask.float()
+        rows, amp = biased_kldiv.biased_kl_from_score(prediction, trg, sampled, score, n_row.expand_as(trg))
+        return rows, [score], [sampled], [amp]
+    score = score * segments.float()
     if stabilize:
-        score = (score - expected_scores) * mask.float()
-    n_row = get_norm_reward_factor(True, mask, segments).expand_as(trg).float()
-    rows, amp = biased_kldiv.biased_kl_from_score(prediction, trg, sampled, score, n_row)
+        with torch.no_grad():
+            p = torch.gather(prediction, 2, sampled.unsqueeze(-1)).squeeze(-1).exp()
+            _, expected = rl_glue.manager_segments(p, expected_scores.float(), segments)
+        score = (score - expected) * mask.float()
+    rows, amp = biased_kldiv.biased_kl_from_segments(prediction, trg, sampled, score, n_row, segments)
     return rows, [score], [sampled], [amp]
 
 
@@ -199,6 +215,27 @@ def bmhrl_validation_next_word_loop(cfg, model, loader, decoder, criterion, epoc
             total += float(torch.sum(criterion(prediction, caption_idx_y)) / n_tokens)
         n += 1
     return total / max(n, 1)
+
+
+def bmhrl_inference(model, feature_stacks, max_len, start_idx, end_idx, pad_idx, modality, captions, batch):
+    """reference :26-28 calls an undefined `inference` (NameError there); the name exists for the importers
+    (sample/single_vid_bmhrl.py:11, scripts/test_model.py:6)"""
+    raise NotImplementedError("bmhrl_inference is broken in the reference (undefined `inference`, :26-28)")
+
+
+def bmhrl_test(cfg, models, loader):
+    """reference :163-186: prints the ground truth and the greedy decode of every batch to stderr (its middle step calls an
+    undefined `bimodal_inference` and is left out)."""
+    import sys
+    cap_model = models["captioning"]
+    ds = loader.dataset
+    sent = lambda idx: " ".join(ds.train_vocab.itos[int(i)] for i in idx)
+    for batch in loader:
+        src = batch['feature_stacks']
+        caption_idx_y = batch['caption_data'].caption[:, 1:]
+        print(f'Groundtruth: {sent(caption_idx_y[0])}', file=sys.stderr)
+        synthesis = bmhrl_greedy_decoder(_unwrap(cap_model), src, cfg.max_len, ds.start_idx, ds.end_idx, ds.pad_idx, cfg.modality)
+        print(f'Greedy Decoder: {sent(synthesis[0])}', file=sys.stderr)
 
 
 def _not_hot_path(*a, **k):

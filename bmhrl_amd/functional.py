@@ -1019,6 +1019,57 @@ class SmoothKLFn(torch.autograd.Function):
         return g.view(B, S, V), None, None, None, None, None, None
 
 
+class ManagerKLFn(torch.autograd.Function):
+    """BiasedKL of the manager branch of biased_kl() (epoch_loops/captioning_bmrl_loops.py:299-334): the amplitude of a
+    position is clamp(score * PROD_{j in its segment} p(a_j) * n_segments, 0, 1) -- the product of the arg-max tokens'
+    probabilities over the segment, still attached to the prediction.  Same kernels as SmoothKLFn: a row's amplitude is
+    written as score * p(a_row) * n_eff with n_eff = n_segments * (segment product / p(a_row)), which gives the value
+    and the gradient through the row's own token; the gradient through the OTHER tokens of the segment is the per-row
+    amplitude gradient (bmhrl_smooth_kl_amp_grad) summed over the segment.  Returns (row sums (B*S,), amplitude (B*S,))."""
+
+    @staticmethod
+    def forward(ctx, logp, trg, biased_trg, score, n_seg, segments, smoothing, pad_idx):
+        from . import rl_glue
+        B, S, V = logp.shape
+        rows = B * S
+        dev = logp.device
+        logp = logp.contiguous()
+        trg = trg.contiguous().view(-1)
+        bt = biased_trg.contiguous().view(-1)
+        p = torch.gather(logp, 2, biased_trg.unsqueeze(-1)).squeeze(-1).exp()            # p(a), (B, S)
+        sid, n_segs, in_seg = rl_glue._segment_layout(segments)
+        segprob = torch.where(in_seg, rl_glue._segment_reduce(p.float(), sid, in_seg, "prod"), torch.zeros_like(p))
+        n_eff = (n_seg.float().expand_as(p) * segprob / p.clamp_min(1e-30)).contiguous().view(-1)
+        sc = score.contiguous().view(-1).float()
+        row_loss = torch.empty(rows, device=dev)
+        amp = torch.empty(rows, device=dev)
+        ops.smooth_kl_fwd(logp, V, trg, bt, sc, n_eff, smoothing, pad_idx, -1, row_loss, amp, rows, V)
+        ctx.save_for_backward(logp, trg, bt, sc, n_eff, sid, in_seg)
+        ctx.cfg = (B, S, V, smoothing, pad_idx)
+        ctx.mark_non_differentiable(amp)
+        return row_loss, amp
+
+    @staticmethod
+    def backward(ctx, drow, _damp):
+        from . import rl_glue
+        B, S, V, smoothing, pad_idx = ctx.cfg
+        logp, trg, bt, sc, n_eff, sid, in_seg = ctx.saved_tensors
+        rows = B * S
+        dev = logp.device
+        one = torch.ones(1, device=dev)
+        g = torch.empty(rows, V, device=dev)
+        ops.smooth_kl_bwd(logp, V, trg, bt, sc, n_eff, smoothing, pad_idx, -1, one, None, 0, g, rows, V, wrt_logits=False)
+        drow = drow.contiguous().view(rows)
+        g = g * drow.view(rows, 1)
+        e = torch.empty(rows, device=dev)
+        ops.smooth_kl_amp_grad(logp, V, trg, bt, sc, n_eff, smoothing, pad_idx, -1, e, rows, V)
+        e = (e * drow).view(B, S)
+        seg_sum = torch.where(in_seg, rl_glue._segment_reduce(e, sid, in_seg, "sum"), torch.zeros_like(e))
+        cross = (seg_sum - torch.where(in_seg, e, torch.zeros_like(e))).view(rows, 1)     # the other tokens of the segment
+        g.scatter_add_(1, bt.view(rows, 1), cross)
+        return g.view(B, S, V), None, None, None, None, None, None, None
+
+
 class ReinforceFn(torch.autograd.Function):
     """-mean(adv.detach * log clamp(p(a), 1e-5, 1-1e-5)) + mean(adv^2), adv = value - critic_value
     (loss/biased_kl.py:69-81; `probs` are probabilities, as the reference passes them)."""

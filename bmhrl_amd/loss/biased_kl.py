@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..functional import SmoothKLFn
+from ..functional import ManagerKLFn, SmoothKLFn
 
 
 class BiasedKL(nn.Module):
@@ -23,6 +23,12 @@ class BiasedKL(nn.Module):
         """Row sums (B*S, 1) of the divergence with amp = clamp(score * p(a) * n_row, 0, 1) attached to pred;
         also returns the amplitude (B, S)."""
         rows, amp = SmoothKLFn.apply(pred, trg, biased_trg, score, n_row, float(self.ls), int(self.pad_idx))
+        return rows.unsqueeze(-1), amp.view(trg.shape)
+
+    def biased_kl_from_segments(self, pred, trg, biased_trg, score, n_seg, segments):
+        """Manager form: amp = clamp(score * prod_{segment} p(a) * n_seg, 0, 1), attached to pred through EVERY token of the
+        segment (reference epoch_loops/captioning_bmrl_loops.py:299-322).  Returns (row sums (B*S, 1), amplitude (B, S))."""
+        rows, amp = ManagerKLFn.apply(pred, trg, biased_trg, score, n_seg, segments, float(self.ls), int(self.pad_idx))
         return rows.unsqueeze(-1), amp.view(trg.shape)
 
     def forward(self, pred, trg, biased_trg, biased_offset, segments=None):

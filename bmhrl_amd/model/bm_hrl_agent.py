@@ -538,6 +538,50 @@ class BMHrlAgent(nn.Module):
         return self.prediction(x, trg, mask)
 
 
+class _OutOfHotPath(nn.Module):
+    """Names of the reference's model/bm_hrl_agent.py that its driver and model/det_bmhrl_agent.py import but that belong to
+    other model families (the unimodal AHRL / VHRL ablation agents, reference :40-51, :133-183, :238-248, :289-325,
+    :664-809; SURVEY.md section 2 row 3: OUT OF SCOPE).  They exist so that `from model.bm_hrl_agent import ...` of the
+    reference's own files resolves after `import bmhrl_amd.install`; constructing one raises."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"{type(self).__name__} (unimodal / projection variants of the reference) is outside the bimodal hot path "
+            "this package replaces; use the reference's own class for it")
+
+
+class ModalityProjection(_OutOfHotPath):
+    pass
+
+
+class UnimodalFusion(_OutOfHotPath):
+    pass
+
+
+class UnimodalFusionLayer(_OutOfHotPath):
+    pass
+
+
+class UnimodalEncoder(_OutOfHotPath):
+    pass
+
+
+class UnimodalEncoderLayer(_OutOfHotPath):
+    pass
+
+
+class UnimodalAgent(_OutOfHotPath):
+    pass
+
+
+class AudioAgent(UnimodalAgent):
+    pass
+
+
+class VideoAgent(UnimodalAgent):
+    pass
+
+
 def agent_state_shapes(cfg, voc_size, with_critic=True):
     """name -> shape of the agent's state dict without building tensors (meta device)."""
     from types import SimpleNamespace

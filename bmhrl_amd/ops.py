@@ -200,6 +200,12 @@ def smooth_kl_bwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, z
                                                _p(g_f32), rows, V, stream()), "bmhrl_smooth_kl_bwd")
 
 
+def smooth_kl_amp_grad(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, out, rows, V):
+    _lib.check(_lib.load().bmhrl_smooth_kl_amp_grad(logp.data_ptr(), ld, trg.data_ptr(), biased_trg.data_ptr(), score.data_ptr(),
+                                                    n_row.data_ptr(), smoothing, pad_idx, zero_pad_rows, out.data_ptr(), rows, V,
+                                                    stream()), "bmhrl_smooth_kl_amp_grad")
+
+
 def log_softmax_bwd(dlogp, logp, ld, g_bf16, ldg, rows, V):
     _lib.check(_lib.load().bmhrl_log_softmax_bwd(dlogp.data_ptr(), logp.data_ptr(), ld, g_bf16.data_ptr(), ldg, rows, V, stream()),
                "bmhrl_log_softmax_bwd")

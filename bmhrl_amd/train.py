@@ -142,6 +142,22 @@ class FlatAdam:
         SHADOWS.invalidate()   # bf16 weight shadows are stale now
 
 
+def token_weight(n_local: torch.Tensor, group=None) -> torch.Tensor:
+    """Weight of this rank's loss in a data-parallel step: n_local * world / n_global.
+
+    The reference normalises by the token count of the WHOLE batch (nn.DataParallel gathers the outputs of all devices and
+    the loop divides the summed loss by the gathered `n_tokens`: scripts/train_rl_captioning_module.py:95-99,
+    utilities/config_constructor.py:94, epoch_loops/captioning_bmrl_loops.py:846-847,1156-1158).  A rank here divides by
+    its own count n_r and the gradients are averaged (sum / world); with the loss of rank r multiplied by
+    n_r * world / sum(n) the average equals sum_r(rows_r) / sum_r(n_r) -- the reference's gradient.  One scalar all-reduce."""
+    n = n_local.detach().to(torch.float32).reshape(1).clone()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return torch.ones((), device=n.device)
+    total = n.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return (n * dist.get_world_size(group) / total.clamp_min(1.0)).reshape(())
+
+
 def trainable_bucket(agent: BMHrlAgent) -> List[torch.nn.Parameter]:
     """Parameters the captioning loss can reach (the reference's optimiser holds all of them, but these are the only
     ones that ever receive a gradient): excludes the frozen critic, the never-applied fusion feed_forward and the
@@ -200,6 +216,7 @@ class CaptionTrainer:
         self.modality = "audio_video"
         self.graph = None
         self.static = None
+        self.loss_weight = torch.ones((), device=self.device)   # token_weight() of the current batch (1 on one rank)
         SEEDS.dev = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------ one step, eager
@@ -215,11 +232,20 @@ class CaptionTrainer:
             n_row = loss_mask.sum(-1, keepdim=True).expand_as(trg_y).float()
             rows, _ = self.rl_criterion.biased_kl_from_score(pred, trg_y, sampled, score, n_row)
             loss = torch.sum(rows) / (n_tokens * (4.0 / 20.0))
+        if self._world_scale() != 1.0:
+            loss = loss * self.loss_weight       # global n_tokens normalisation (token_weight); a device scalar: graph-safe
         return loss, pred
+
+    def _sync_token_weight(self, captions):
+        """before a step: this rank's share of the global token count -> self.loss_weight (in place: the captured step
+        reads the same device scalar)"""
+        if self._world_scale() != 1.0:
+            self.loss_weight.copy_(token_weight((captions[:, 1:] != self.pad_idx).sum()))
 
     def step(self, fs, captions, rl=None):
         """zero_grad -> forward -> loss -> backward -> (all-reduce) -> Adam.  Returns the loss (device scalar)."""
         trg_in, trg_y = captions[:, :-1].contiguous(), captions[:, 1:].contiguous()
+        self._sync_token_weight(captions)
         self.opt.zero_grad()
         SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
@@ -244,6 +270,7 @@ class CaptionTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
+                self._sync_token_weight(self.static["captions"])
                 self._graph_body_a()
                 if self._split():
                     for j in range(1, self.n_enc + 1):
@@ -337,6 +364,7 @@ class CaptionTrainer:
             for k in ("rgb", "flow", "audio"):
                 self.static[k].copy_(fs[k])
             self.static["captions"].copy_(captions)
+        self._sync_token_weight(self.static["captions"])
         self.graph_a.replay()
         if self.graph_b is None:                  # single process: forward, backward and Adam are one graph
             return self.static_loss

@@ -204,6 +204,12 @@ int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const
                         void* grad_bf16, int64_t ldg, float* grad_f32, int64_t rows, int32_t V, bmhrl_stream_t stream);
 int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, void* dlogits_bf16, int64_t ldg,
                           int64_t rows, int32_t V, bmhrl_stream_t stream);
+/* out[row] = d rowloss / d log(raw amplitude) (0 where clamp(., 0, 1) is active): the share of the gradient that reaches the
+ * row through its amplitude.  Manager branch of biased_kl(), epoch_loops/captioning_bmrl_loops.py:299-317: the amplitude holds
+ * the product of p(a) over a segment, so this also flows to the segment's other tokens (bmhrl_amd/functional.py ManagerKLFn). */
+int bmhrl_smooth_kl_amp_grad(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg, const float* score,
+                             const float* n_row, float smoothing, int32_t pad_idx, int32_t zero_pad_rows, float* out,
+                             int64_t rows, int32_t V, bmhrl_stream_t stream);
 /* a ~ Categorical(exp(logp)) by inverse CDF with one uniform per row (counter RNG: seed, row);
  * greedy != 0 -> argmax.  epoch_loops/captioning_bmrl_loops.py:283-284 */
 int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,

@@ -394,6 +394,26 @@ def worker_biased_kl(pred: Tensor, trg: Tensor, sampled: Tensor, score: Tensor, 
     return biased_kl_loss(pred, trg, sampled, amp, smoothing, pad_idx), score
 
 
+def manager_biased_kl(pred: Tensor, trg: Tensor, score: Tensor, baseline: Tensor, loss_mask: Tensor, segments: Tensor,
+                      smoothing: float, pad_idx: int, stabilize: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Manager branch of ``biased_kl`` with the reward given (epoch_loops/captioning_bmrl_loops.py:271-334,
+    train_worker=False): arg-max tokens (:283-284), ``score * segments`` (:300), per-segment product of the arg-max
+    probabilities and per-segment sum of the expected scores by the Python loop (:301-316, ``manager_segment_loop``),
+    optional baseline subtraction (:318-319), norm factor = segments per row (:414-416); the amplitude stays attached to
+    ``pred`` through every probability of the product.
+    Returns (unreduced divergence (B*S, V), score, arg-max tokens, amplitude)."""
+    probs = torch.exp(pred)
+    sampled = torch.argmax(probs, dim=-1)
+    p = torch.gather(probs, 2, sampled.unsqueeze(-1)).squeeze(-1)
+    n = segments.sum(dim=-1).reshape(-1, 1)
+    score = score.float() * segments.float()
+    seg_prob, expected = manager_segment_loop(p, baseline.float(), segments)
+    if stabilize:
+        score = (score - expected) * loss_mask.float()
+    amp = amplitude(score, seg_prob, n)
+    return biased_kl_loss(pred, trg, sampled, amp, smoothing, pad_idx), score, sampled, amp
+
+
 def warmstart_loss(pred: Tensor, trg_y: Tensor, smoothing: float, pad_idx: int) -> Tensor:
     """sum(LabelSmoothing) / n_tokens.  epoch_loops/captioning_bmrl_loops.py:1156-1158."""
     n_tokens = (trg_y != pad_idx).sum()

@@ -243,18 +243,23 @@ def sample_clip_decode():
         feats[k] = crop_a_segment(a, 0, 15, 16).unsqueeze(0)
     trg = torch.full((1, 1), 2, dtype=torch.long)
     first = None
+    margins, top_logp = [], []           # per step: the reference's own top-1 / top-2 gap and the chosen token's log-prob
     with torch.no_grad(), quiet:
         while trg.shape[-1] <= 12:
             masks = make_masks(feats, trg, "audio_video", 1)
             pred = agent.inference((feats["rgb"] + feats["flow"], feats["audio"]), trg, masks)
             if first is None:
                 first = pred[0, -1].clone()
+            t2 = torch.topk(pred[0, -1], 2).values
+            margins.append(float(t2[0] - t2[1]))
+            top_logp.append(float(t2[0]))
             nxt = pred[:, -1].argmax(-1, keepdim=True)
             trg = torch.cat([trg, nxt], -1)
     top2 = torch.topk(first, 2).values
     np.savez_compressed(os.path.join(HERE, "sample_clip.npz"), rgb=np_(feats["rgb"]),
                         flow=np_(feats["flow"]), audio=np_(feats["audio"]),
-                        tokens=np_(trg), first_logp=np_(first), first_margin=np_(top2[0] - top2[1]), voc=np.array(Vsz))
+                        tokens=np_(trg), first_logp=np_(first), first_margin=np_(top2[0] - top2[1]), voc=np.array(Vsz),
+                        margins=np.array(margins, dtype=np.float32), top_logp=np.array(top_logp, dtype=np.float32))
 
 
 def detr_cases():
@@ -399,9 +404,48 @@ def loader_cases():
     np.savez_compressed(os.path.join(HERE, "loader.npz"), **res)
 
 
+def value_function_cases():
+    """BMWorkerValueFunction / BMManagerValueFunction (reference model/bm_hrl_agent.py:251-286), eval mode: outputs at the
+    default widths (d_model_caps 300 -> 600 -> 300 -> 1) and, at width 48 (small fixture), the masked-MSE loss against a
+    given score (epoch_loops/captioning_bmrl_loops.py:873-876) with every parameter gradient."""
+    from model.bm_hrl_agent import BMManagerValueFunction, BMWorkerValueFunction
+    out = {}
+    for d, with_grads in ((300, False), (48, True)):
+        cfg = syn.tiny_cfg()
+        cfg.d_model_caps, cfg.rl_goal_d, cfg.dout_p = d, 64, 0.1
+        g = torch.Generator().manual_seed(21 + d)
+        B, L = 3, 6
+        feat = torch.randn(B, L, d, generator=g)
+        goal = torch.randn(B, L, 64, generator=g)
+        score = torch.rand(B, L, generator=g)
+        mask = (torch.rand(B, L, generator=g) < 0.8).float()
+        out.update({f"d{d}/feat": np_(feat), f"d{d}/goal": np_(goal), f"d{d}/score": np_(score), f"d{d}/mask": np_(mask)})
+        for name, cls in (("worker", BMWorkerValueFunction), ("manager", BMManagerValueFunction)):
+            m = cls(cfg)
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            m.load_state_dict(syn.fill_state_dict(shapes, seed=31 if name == "worker" else 32))
+            m.eval()
+            y = m((feat, goal)) if name == "worker" else m(feat)
+            out[f"d{d}/{name}/out"] = np_(y)
+            out[f"d{d}/{name}/keys"] = np.array(sorted(shapes))
+            if with_grads:
+                loss = (torch.nn.MSELoss(reduction="none")(y.squeeze(-1), score) * mask).mean()
+                loss.backward()
+                out[f"d{d}/{name}/loss"] = np_(loss)
+                for k, v in m.named_parameters():
+                    out[f"d{d}/{name}/grad/{k}"] = np_(v.grad)
+    np.savez_compressed(os.path.join(HERE, "value_fn.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--only-value" in sys.argv:
+        value_function_cases()
+        sys.exit(0)
+    if "--only-sample" in sys.argv:
+        sample_clip_decode()
+        sys.exit(0)
     kat()
     losses_random()
     mha_cases()
@@ -411,6 +455,7 @@ if __name__ == "__main__":
     detr_cases()
     rl_glue_cases()
     loader_cases()
+    value_function_cases()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

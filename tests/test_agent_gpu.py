@@ -125,63 +125,130 @@ def test_tiny_agent_warmstart_and_rl_gradients(dev, golden):
 
 
 def test_sample_clip_greedy_decode_config1(dev, golden):
-    """BASELINE config 1 through the HIP path: tokens of the reference while its own top-2 margin exceeds the bf16
-    tolerance, and the first-step log-probs within 1e-3 relative."""
+    """BASELINE config 1 through the HIP path, keyed to the reference's own per-step top-1 / top-2 margins
+    (tests/golden/sample_clip.npz): fed the reference's token prefix, every step's arg-max must be the reference's token
+    unless the reference's margin at that step is below the bf16 tolerance (2e-2 in log-prob units), and the chosen token's
+    log-prob must agree within 1e-3 relative at every step; the free-running greedy decode must reproduce the reference's
+    tokens up to the first such low-margin step."""
     from bmhrl_amd.decode import greedy_decode
+    from bmhrl_amd.model.masking import make_masks
     g = golden("sample_clip")
     cfg = syn.default_cfg(dout_p=0.0, rl_critic_score_threshhold=1.0)
     agent, _ = build_agent(cfg, int(g["voc"]), dev)
     fs = {k: T(g[k]).to(dev) for k in ("rgb", "flow", "audio")}
+    ref = T(g["tokens"]).long()                        # (1, 13): <s> + 12 generated tokens
+    margins, top_logp = g["margins"], g["top_logp"]
+    tol = 2e-2
+    # teacher forced: one forward over the reference's prefix gives the log-probs of every step
+    trg = ref[:, :-1].to(dev)
+    with torch.no_grad():
+        preds = agent.inference(((fs["rgb"], fs["flow"]), fs["audio"]), trg, make_masks(fs, trg, "audio_video", 1))
+    got = preds[0].argmax(-1).cpu()
+    for step in range(ref.shape[1] - 1):
+        chosen = float(preds[0, step, ref[0, step + 1]])
+        assert abs(chosen - float(top_logp[step])) <= 1e-3 * abs(float(top_logp[step])), (step, chosen, float(top_logp[step]))
+        if margins[step] > tol:
+            assert int(got[step]) == int(ref[0, step + 1]), (step, float(margins[step]))
+    assert (margins > tol).sum() >= 9                  # the fixture decides most steps clearly
     toks, first = greedy_decode(agent, fs, 12, 2, 3, 1, "audio_video", return_first=True)
     assert rel(first[0], g["first_logp"]) < 1e-3
-    ref = g["tokens"]
-    n = ref.shape[1]
-    got = toks.cpu().numpy()[:, :n]
-    # the reference's own margin at step 0 says whether an arg-max flip is within tolerance
-    if float(g["first_margin"]) > 2e-2:
-        assert got[0, 1] == ref[0, 1]
-    assert got.shape == ref.shape and (got == ref).mean() >= 0.5
+    low = np.nonzero(margins <= tol)[0]
+    n_sure = int(low[0]) if len(low) else len(margins)  # steps before the first coin-flip of the reference itself
+    assert np.array_equal(toks.cpu().numpy()[0, :n_sure + 1], g["tokens"][0, :n_sure + 1])
 
 
-def test_full_size_forward_vs_oracle(dev):
-    """d_model 1024, H 4, N 2, Tv 256, Ta 800 (BASELINE config 2 shapes, B=2 to keep the CPU oracle to seconds)."""
+def rel_elem(a, b, floor=1.0):
+    """per-element relative error max |a-b| / max(|b|, floor): the strict reading of north_star's "within 1e-3 relative"
+    ("max rel. error on logits with |logit| floor"); log-probs span about [-12, 0], floor 1.0"""
+    a = a.detach().double().cpu()
+    b = (b if isinstance(b, torch.Tensor) else T(np.asarray(b))).double()
+    return float(((a - b).abs() / b.abs().clamp_min(floor)).max())
+
+
+WATCH = ["bm_enc.encoder.layers.0.self_att_M1.linear_Q2d.weight", "bm_enc.encoder.layers.0.self_att_M2.linear_V2d.weight",
+         "bm_enc.encoder.layers.0.bi_modal_att_M1.linear_K2d.weight", "bm_enc.encoder.layers.1.bi_modal_att_M2.linear_Q2d.weight",
+         "bm_enc.encoder.layers.0.feed_forward_M1.fc1.weight", "bm_enc.encoder.layers.1.res_layers_M2.1.norm.weight",
+         "bm_worker_fus.decoder.layers.0.enc_att_V.linear_V2d.weight", "bm_manager_fus.decoder.layers.1.self_att.linear_Q2d.weight",
+         "bm_worker_fus.decoder.layers.1.a_v_constant", "manager.linear.weight", "worker.goal_attention.linear_d2Q.weight",
+         "worker.core.projection.weight", "emb_C.embedder.weight"]
+
+
+def _forward_backward_vs_oracle(dev, B, Tv, Ta, n_layers, with_grads, extra_watch=()):
+    """log-probs / features / integer segment labels (and the warmstart loss + the watched gradients) of the HIP path
+    against the CPU oracle on the same synthetic batch and weights.  Returns the measured errors (printed by pytest -s)."""
     from oracle import bmhrl_oracle as O
     from bmhrl_amd.model.masking import make_masks
-    cfg = syn.default_cfg(dout_p=0.0)
+    from bmhrl_amd.loss.label_smoothing import LabelSmoothing
+    cfg = syn.default_cfg(dout_p=0.0, rl_att_layers=n_layers)
     V = 10172
     agent, sd = build_agent(cfg, V, dev)
-    B, Tv, Ta, L = 2, 256, 800, 30
+    L = 30
     b = syn.synthetic_batch(B, Tv, Ta, L, V, seed=0)
     b["rgb"][1, Tv - 40:] = 0; b["flow"][1, Tv - 40:] = 0; b["audio"][1, Ta - 100:] = 0
     cap = b["captions"]
-    trg_in = cap[:, :-1].contiguous()
-    ref = O.agent_forward(sd, cfg, (b["rgb"] + b["flow"], b["audio"]), trg_in, O.make_masks(b["rgb"], b["audio"], trg_in, 1))
+    trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
+    watch = list(WATCH) + list(extra_watch)
+    sdr = {k: (v.clone().requires_grad_(True) if (with_grads and k in watch) else v) for k, v in sd.items()}
+    with torch.set_grad_enabled(with_grads):
+        ref = O.agent_forward(sdr, cfg, (b["rgb"] + b["flow"], b["audio"]), trg_in, O.make_masks(b["rgb"], b["audio"], trg_in, 1))
     fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
     masks = make_masks(fs, trg_in.to(dev), "audio_video", 1)
-    out = agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in.to(dev), masks)
-    assert np.array_equal(out[4].cpu().numpy(), ref[4].numpy())
-    assert rel(out[0], ref[0]) < 1e-3
-    assert rel(out[1], ref[1]) < 1e-2 and rel(out[2], ref[2]) < 1e-2 and rel(out[3], ref[3]) < 1e-2
-    # warmstart-step gradients at full width against the oracle's autograd (relative L2 per tensor <= 1e-2 ... 2e-2)
-    from bmhrl_amd.loss.label_smoothing import LabelSmoothing
-    trg_y = cap[:, 1:].contiguous()
-    loss = torch.sum(LabelSmoothing(0.7, 1)(out[0], trg_y.to(dev))) / (trg_y != 1).sum().to(dev)
-    loss.backward()
-    watch = ["bm_enc.encoder.layers.0.self_att_M1.linear_Q2d.weight", "bm_enc.encoder.layers.0.self_att_M2.linear_V2d.weight",
-             "bm_enc.encoder.layers.0.bi_modal_att_M1.linear_K2d.weight", "bm_enc.encoder.layers.1.bi_modal_att_M2.linear_Q2d.weight",
-             "bm_enc.encoder.layers.0.feed_forward_M1.fc1.weight", "bm_enc.encoder.layers.1.res_layers_M2.1.norm.weight",
-             "bm_worker_fus.decoder.layers.0.enc_att_V.linear_V2d.weight", "bm_manager_fus.decoder.layers.1.self_att.linear_Q2d.weight",
-             "bm_worker_fus.decoder.layers.1.a_v_constant", "manager.linear.weight", "worker.goal_attention.linear_d2Q.weight",
-             "worker.core.projection.weight", "emb_C.embedder.weight"]
-    sdr = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
-    ref_pred = O.agent_forward(sdr, cfg, (b["rgb"] + b["flow"], b["audio"]), trg_in, O.make_masks(b["rgb"], b["audio"], trg_in, 1))[0]
-    ref_loss = O.warmstart_loss(ref_pred, trg_y, 0.7, 1)
-    ref_loss.backward()
-    assert rel(loss, ref_loss) < 1e-3
-    named = dict(agent.named_parameters())
-    for k in watch:
-        e = rel_l2(named[k].grad, sdr[k].grad)
-        assert e < 2e-2, (k, e)
+    with torch.set_grad_enabled(with_grads):
+        out = agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in.to(dev), masks)
+    assert np.array_equal(out[4].cpu().numpy(), ref[4].numpy())                    # int32 segment labels: exact
+    errs = {"logp_maxnorm": rel(out[0], ref[0].detach()), "logp_elem_floor1": rel_elem(out[0], ref[0].detach())}
+    assert errs["logp_maxnorm"] < 1e-3, errs
+    # per element, relative, |log-prob| floor 1.0 (the strict reading of north_star's 1e-3): measured 7.1e-4 (B=2) and 7.4e-4
+    # (B=16) at config 2 on MI355X; deeper stacks (N=6) and the long-segment shapes get the bound below
+    assert errs["logp_elem_floor1"] < (1e-3 if n_layers <= 2 and Ta <= 800 else 3e-3), errs
+    assert rel(out[1], ref[1].detach()) < 1e-2 and rel(out[2], ref[2].detach()) < 1e-2 and rel(out[3], ref[3].detach()) < 1e-2
+    if with_grads:
+        loss = torch.sum(LabelSmoothing(0.7, 1)(out[0], trg_y.to(dev))) / (trg_y != 1).sum().to(dev)
+        loss.backward()
+        ref_loss = O.warmstart_loss(ref[0], trg_y, 0.7, 1)
+        ref_loss.backward()
+        errs["loss"] = rel(loss, ref_loss.detach())
+        assert errs["loss"] < 1e-3, errs
+        named = dict(agent.named_parameters())
+        for k in watch:
+            e = rel_l2(named[k].grad, sdr[k].grad)
+            errs["grad:" + k] = e
+            # Score-path weights (Q2d / K2d) of the caption -> memory attentions: 30 queries over 256 / 800 keys with a
+            # near-uniform softmax at random init -- their gradient is the residual of a cancellation (rows of dS sum to
+            # zero, the memory rows share a large common component), 100x smaller in norm than the value-path gradients of
+            # the same block, and carries the bf16 rounding of P / dS at 6-13 % of its own norm (measured on MI355X, N=6).
+            score_path = ".enc_att_" in k and (k.endswith("linear_K2d.weight") or k.endswith("linear_Q2d.weight"))
+            assert e < (1.5e-1 if score_path else 2e-2), (k, e)
+    print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in errs.items() if not k.startswith("grad:")},
+          "worst grad rel-L2", max([v for k, v in errs.items() if k.startswith("grad:")] or [0.0]))
+    return errs
+
+
+def test_full_size_forward_vs_oracle(dev):
+    """d_model 1024, H 4, N 2, Tv 256, Ta 800 (BASELINE config 2 shapes) at B=2: log-probs, features, labels, warmstart
+    loss and 13 watched gradients (first-layer weights included) against the oracle's autograd."""
+    _forward_backward_vs_oracle(dev, 2, 256, 800, 2, True)
+
+
+def test_config2_full_batch_vs_oracle(dev):
+    """The bench workload itself -- BASELINE configs[1]: B=16, Tv=256, Ta=800, L=30, V=10 172, N=2 -- against the oracle
+    directly (a few seconds of CPU): log-probs, loss and the 13 watched gradients."""
+    _forward_backward_vs_oracle(dev, 16, 256, 800, 2, True)
+
+
+def test_config4_six_layers_vs_oracle(dev):
+    """BASELINE configs[3]: the ActivityNet shapes with N = 6 encoder / fusion layers (d_model 1024, H 4), one GPU, B=2:
+    forward and backward against the oracle, the deepest and the first layer's weights among the watched gradients."""
+    _forward_backward_vs_oracle(dev, 2, 256, 800, 6, True,
+                                extra_watch=["bm_enc.encoder.layers.5.bi_modal_att_M1.linear_Q2d.weight",
+                                             "bm_enc.encoder.layers.3.feed_forward_M2.fc2.weight",
+                                             "bm_worker_fus.decoder.layers.5.enc_att_A.linear_K2d.weight"])
+
+
+def test_config5_long_segments_forward_vs_oracle(dev):
+    """BASELINE configs[4] shapes (Tv=1024, Ta=2048) at B=2, forward: the audio-keyed attentions (Sk = 2048) stay on the
+    fused head-dimension-128 kernel (no key-count limit), the video-keyed ones on the head-dimension-256 kernel."""
+    _forward_backward_vs_oracle(dev, 2, 1024, 2048, 2, False)
 
 
 def test_full_batch_consistent_with_oracle_checked_chunks(dev):
@@ -229,3 +296,38 @@ def test_full_batch_consistent_with_oracle_checked_chunks(dev):
     assert rel(loss_sum, loss_acc.cpu()) < 1e-3
     for k in watch:
         assert rel_l2(grads[k], acc[k].cpu()) < 2e-2, k
+
+
+def test_value_functions_match_the_reference(golden):
+    """BMWorkerValueFunction / BMManagerValueFunction on the HIP path against the reference's own outputs and parameter
+    gradients (model/bm_hrl_agent.py:251-286, masked MSE of epoch_loops/captioning_bmrl_loops.py:873-876;
+    tests/golden/value_fn.npz).  bf16 MFMA operands, fp32 accumulate: outputs <= 1e-2 of max|ref| (a 300-term projection whose
+    terms largely cancel: measured 5.2e-3), gradients <= 2e-2 (rel. L2)."""
+    from bmhrl_amd.model.bm_hrl_agent import BMManagerValueFunction, BMWorkerValueFunction
+    z = golden("value_fn")
+    dev = torch.device("cuda:0")
+    for d in (300, 48):
+        cfg = syn.tiny_cfg()
+        cfg.d_model_caps, cfg.rl_goal_d, cfg.dout_p = d, 64, 0.1
+        feat = torch.from_numpy(z[f"d{d}/feat"]).to(dev)
+        goal = torch.from_numpy(z[f"d{d}/goal"]).to(dev)
+        score = torch.from_numpy(z[f"d{d}/score"]).to(dev)
+        mask = torch.from_numpy(z[f"d{d}/mask"]).to(dev)
+        for name, cls, seed in (("worker", BMWorkerValueFunction, 31), ("manager", BMManagerValueFunction, 32)):
+            m = cls(cfg)
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            assert sorted(shapes) == [str(k) for k in z[f"d{d}/{name}/keys"]]
+            m.load_state_dict(syn.fill_state_dict(shapes, seed=seed))
+            m.to(dev).eval()
+            y = m((feat, goal)) if name == "worker" else m(feat)
+            ref = torch.from_numpy(z[f"d{d}/{name}/out"])
+            assert y.shape == ref.shape
+            assert float((y.detach().cpu() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()), (d, name)
+            if f"d{d}/{name}/loss" in z:
+                loss = (torch.nn.MSELoss(reduction="none")(y.squeeze(-1), score) * mask).mean()
+                loss.backward()
+                assert abs(float(loss) - float(z[f"d{d}/{name}/loss"])) <= 1e-2 * abs(float(z[f"d{d}/{name}/loss"]))
+                for k, v in m.named_parameters():
+                    g = torch.from_numpy(z[f"d{d}/{name}/grad/{k}"])
+                    err = float((v.grad.cpu() - g).norm() / g.norm().clamp_min(1e-12))
+                    assert err <= 2e-2, (d, name, k, err)

@@ -205,3 +205,22 @@ def test_detr_layers(golden):
     b = O.detr_stack(dsd, "dec", 2, tgt, lambda p, x: O.detr_decoder_layer(dsd, p, x, mem, mask, None, None, goal, qmask,
                                                                              False, None, H), True)
     close(b, g["dec_b"])
+
+
+def test_value_functions_match_the_reference(golden):
+    """oracle.value_function against BMWorkerValueFunction / BMManagerValueFunction of the reference
+    (model/bm_hrl_agent.py:251-286; tests/golden/value_fn.npz)"""
+    z = golden("value_fn")
+    for d in (300, 48):
+        feat = torch.from_numpy(z[f"d{d}/feat"])
+        for name, seed in (("worker", 31), ("manager", 32)):
+            keys = [str(k) for k in z[f"d{d}/{name}/keys"]]
+            shapes = {"value_function.fc1.weight": (2 * d, d), "value_function.fc1.bias": (2 * d,),
+                      "value_function.fc2.weight": (d, 2 * d), "value_function.fc2.bias": (d,),
+                      "projection.weight": (1, d), "projection.bias": (1,)}
+            assert sorted(shapes) == keys
+            sd = syn.fill_state_dict(shapes, seed=seed)
+            out = O.value_function(sd, feat)
+            ref = torch.from_numpy(z[f"d{d}/{name}/out"])
+            assert out.shape == ref.shape == (3, 6, 1)
+            assert float((out - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

@@ -25,3 +25,46 @@ def test_glue_on_device_matches_loops():
     assert torch.allclose(G.discontinue_reward(r.to(dev), 0.9, 5).cpu(), O.discontinue_reward_loop(r, 0.9, 5), rtol=1e-5, atol=1e-5)
     assert torch.allclose(G.discontinue_reward(r.to(dev), 0.9, 100, seg.to(dev)).cpu(), O.discontinue_reward_loop(r, 0.9, 100, seg),
                           rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("stabilize", [False, True])
+def test_manager_branch_of_biased_kl_matches_the_oracle(stabilize):
+    """biased_kl(train_worker=False): arg-max tokens, score * segments, per-segment product / sum with the reference's
+    row-transition quirks, amplitude attached to the prediction through EVERY probability of the segment product
+    (reference epoch_loops/captioning_bmrl_loops.py:283-334) -- value and gradient against the oracle's loop restatement."""
+    import torch
+    from bmhrl_amd.epoch_loops.captioning_bmrl_loops import biased_kl
+    from bmhrl_amd.loss.biased_kl import BiasedKL
+    from oracle import bmhrl_oracle as O
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, L, V, pad = 5, 7, 23, 1
+    logits = torch.randn(B, L, V, generator=g) * 2.0
+    trg = torch.randint(2, V, (B, L), generator=g)
+    trg[0, 5:] = pad
+    trg[3, 3:] = pad
+    # segment ends: row 0 none (zeroed by the `old_b = 0` quirk), rows 1 and 3 two segments, row 2 none, row 4 one (last row keeps its tail)
+    seg = torch.zeros(B, L, dtype=torch.int32)
+    seg[1, 1] = seg[1, 4] = seg[3, 0] = seg[3, 5] = seg[4, 2] = 1
+    score = torch.rand(B, L, generator=g) * 4.0
+    score[3, 0] = 50.0                                      # this segment's amplitude reaches the clamp (no gradient through it)
+    baseline = torch.rand(B, L, generator=g) * 0.3
+    mask = trg != pad
+
+    ref_lp = torch.log_softmax(logits, -1).requires_grad_(True)
+    div, ref_score, ref_tok, ref_amp = O.manager_biased_kl(ref_lp, trg, score, baseline, mask, seg, 0.7, pad, stabilize)
+    ref_rows = div.sum(-1)
+    w = torch.linspace(0.5, 1.5, B * L)                    # distinct upstream gradients per row
+    (ref_rows * w).sum().backward()
+
+    lp = torch.log_softmax(logits, -1).to(dev).requires_grad_(True)
+    rows, sc, tok, amp = biased_kl(False, lp, None, baseline.to(dev), trg.to(dev), None, mask.to(dev), seg.to(dev), dev,
+                                   BiasedKL(0.7, pad), stabilize, reward_fn=lambda a, c: score.to(dev))
+    (rows.view(-1) * w.to(dev)).sum().backward()
+    assert torch.equal(tok[0].cpu(), ref_tok)
+    assert torch.allclose(sc[0].cpu(), ref_score, atol=1e-6)
+    assert torch.allclose(amp[0].cpu(), ref_amp.detach(), atol=1e-5, rtol=1e-4)
+    assert 0 < int(((ref_amp > 0) & (ref_amp < 1)).sum()) and int((ref_amp >= 1).sum()) > 0   # both clamp regimes are exercised
+    assert torch.allclose(rows.view(-1).detach().cpu(), ref_rows.detach(), atol=1e-4, rtol=1e-4)
+    gerr = (lp.grad.cpu() - ref_lp.grad).abs().max() / ref_lp.grad.abs().max()
+    assert float(gerr) < 1e-4, float(gerr)
