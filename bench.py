@@ -7,9 +7,9 @@ d_model=1024, H=4, dropout 0.1 in train mode (BASELINE.json configs[1]).  Inputs
 region.  One process per GPU; for N > 1 launch with torch.distributed.run (RCCL all-reduce of the flat gradient bucket).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     -- the cross-modal attention kernel (V<-A: B16 H4 Sq256 Sk800 d_k256), algorithmic 4*B*Sq*Sk*D flops per
-                  launch / mean launch time measured here with HIP events on the launch stream, vs the 2.5 PFLOP/s
-                  dense bf16 MFMA peak,
+  roofline     -- the cross-modal attention kernels (V<-A: B16 H4 Sq256 Sk800; A<-V: Sq800 Sk256) with the step's padded
+                  masks: flops EXECUTED per launch / mean launch time measured here with HIP events on the launch
+                  stream, vs the 2.5 PFLOP/s dense bf16 MFMA peak (attention_roofline()),
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's arithmetic) timed on this host on a bounded sample.
 """
 import argparse
@@ -57,52 +57,106 @@ def _time_launches(fn, iters):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def attention_roofline(dev, B, H, Sq, Sk, iters=50):
-    """Mean launch time of the kernel that computes the cross-modal video<-audio attention of a step, at the step's own
-    shape, HIP events on torch's current stream (the stream the kernel is launched on).
+def _pad_mask(B, S, dev):
+    """key mask of the synthetic batch (bmhrl_amd.synthetic.synthetic_batch): the last (37 b) mod (S/4) positions of
+    sample b are padding"""
+    m = torch.ones(B, S, dtype=torch.bool)
+    for b in range(B):
+        r = (37 * b) % max(S // 4, 1)
+        if r:
+            m[b, S - r:] = False
+    return m.to(dev)
 
-    Since r01 that attention runs in the absorbed-projection form: keys / values are the 128-wide
-    audio rows themselves, shared by all heads, and the d_model-wide K / V projections act on the query side.
-    `achieved` follows the contract: ALGORITHMIC flops of the attention call it replaces (4*B*Sq*Sk*D with
-    D = H*d_k = 1024) over the launch time; the flops the kernel actually executes (half of that) and the two small
-    GEMMs the form adds next to it (Q_h Wk_h before, context Wv_h^T after) are reported alongside."""
+
+def attention_roofline(dev, B, H, Tv, Ta, iters=50):
+    """The two cross-modal attention launches of an encoder layer at the step's own shapes and with the step's own padded
+    key masks, each timed with HIP events on the stream it is launched on (torch's current stream):
+
+      V<-A  bmhrl_attention_shared128_fwd -> attn_fwd_kernel<128, ...>: queries = video rows (Sq = Tv), keys / values = the
+            128-wide audio rows shared by all heads (absorbed-projection form).  The launch EXECUTES
+            4*B*H*Sq*Sk*128 flops (half of the 4*B*Sq*Sk*1024 of the attention call it stands for);
+      A<-V  bmhrl_attention_fwd -> attn_fwd_kernel<256, ...>: queries = audio rows (Sq = Ta), keys / values = video rows,
+            d_k = 256: executes the full 4*B*Sq*Sk*1024.
+
+    `frac` (the headline) = flops EXECUTED by the V<-A launch / its time / the 2.5 PFLOP/s dense bf16 MFMA peak (padded
+    positions count as full work).  The A<-V launch, the call-equivalent figure of V<-A (the attention call's
+    flops over kernel + the two query-side projection GEMMs the form adds, timed together) and the MFMA work actually
+    issued (key tiles behind the last valid key of a batch row are not visited) are reported next to it."""
     from bmhrl_amd import ops
     dk, D, dm = 256, H * 256, 128
     g = torch.Generator(device="cpu").manual_seed(0)
+    scale = dk ** -0.5
+    a_mask, v_mask = _pad_mask(B, Ta, dev), _pad_mask(B, Tv, dev)
+
+    # ---- V<-A (head dimension 128, shared keys / values)
+    Sq, Sk = Tv, Ta
     Qp = (0.5 * torch.randn(B, Sq, H, dm, generator=g)).to(dev).to(torch.bfloat16)
     X = torch.randn(B, Sk, dm, generator=g).to(dev).to(torch.bfloat16)
-    mask = torch.ones(B, Sk, dtype=torch.bool, device=dev)
     ctx = torch.empty(B, Sq, H, dm, dtype=torch.bfloat16, device=dev)
     rmax = torch.empty(B, H, Sq, device=dev)
     rsum = torch.empty(B, H, Sq, device=dev)
-    sec = _time_launches(lambda: ops.attention_shared128_fwd(Qp, X, ctx, rmax, rsum, mask, Sk, B, H, Sq, Sk, dk ** -0.5,
-                                                             H * dm, dm, H * dm), iters)
-    # the two GEMMs the absorbed form adds around the kernel (it removes the 2*B*Sk*128*2048-flop K|V projection)
+    va = lambda: ops.attention_shared128_fwd(Qp, X, ctx, rmax, rsum, a_mask, Sk, B, H, Sq, Sk, scale, H * dm, dm, H * dm)
+    sec_va = _time_launches(va, iters)
+    # the call the launch stands for: Q'_h = Q_h Wk_h before, O_h = context_h Wv_h^T after (it removes the K|V projection
+    # of the B*Sk audio rows), timed together with the kernel
     rows = B * Sq
     Qb = torch.randn(rows, D, generator=g).to(dev).to(torch.bfloat16)
     Wk = torch.randn(D, dm, generator=g).to(dev).to(torch.bfloat16)
     Ob = torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
     Qp2 = Qp.view(rows, H * dm)
-    sec_q = _time_launches(lambda: ops.gemm(Qb, Wk, rows, dm, dk, lda=D, ldb=dm, b_trans=True, batch=(1, H), a_strides=(0, dk),
-                                            b_strides=(0, dk * dm), C_bf16=Qp2, ldcb=H * dm, cb_strides=(0, dm)), iters)
-    sec_o = _time_launches(lambda: ops.gemm(Qp2, Wk, rows, dk, dm, lda=H * dm, ldb=dm, batch=(1, H), a_strides=(0, dm),
-                                            b_strides=(0, dk * dm), C_bf16=Ob, ldcb=D, cb_strides=(0, dk)), iters)
-    flops = 4.0 * B * Sq * Sk * D               # the attention call this launch stands for (SURVEY 8d)
-    executed = 4.0 * B * H * Sq * Sk * dm
+    ctx2 = ctx.view(rows, H * dm)
+
+    def va_call():
+        ops.gemm(Qb, Wk, rows, dm, dk, lda=D, ldb=dm, b_trans=True, batch=(1, H), a_strides=(0, dk), b_strides=(0, dk * dm),
+                 C_bf16=Qp2, ldcb=H * dm, cb_strides=(0, dm))
+        va()
+        ops.gemm(ctx2, Wk, rows, dk, dm, lda=H * dm, ldb=dm, batch=(1, H), a_strides=(0, dm), b_strides=(0, dk * dm),
+                 C_bf16=Ob, ldcb=D, cb_strides=(0, dk))
+    sec_call = _time_launches(va_call, iters)
+    exec_va = 4.0 * B * H * Sq * Sk * dm
+    call_va = 4.0 * B * Sq * Sk * D
+    # MFMA work actually issued: the kernel visits the 64-key tiles up to the last valid key of a batch row
+    visited = sum(min(Sk, -(-int(a_mask[b].sum()) // 64) * 64) for b in range(B))
+    issued_va = 4.0 * H * Sq * visited * dm
+
+    # ---- A<-V (head dimension 256)
+    Sq2, Sk2 = Ta, Tv
+    Q2 = torch.randn(B, Sq2, D, generator=g).to(dev).to(torch.bfloat16)
+    K2 = torch.randn(B, Sk2, D, generator=g).to(dev).to(torch.bfloat16)
+    V2 = torch.randn(B, Sk2, D, generator=g).to(dev).to(torch.bfloat16)
+    O2 = torch.empty(B, Sq2, D, dtype=torch.bfloat16, device=dev)
+    rmax2 = torch.empty(B, H, Sq2, device=dev)
+    rsum2 = torch.empty(B, H, Sq2, device=dev)
+    av = lambda: ops.attention_fwd(Q2, K2, V2, O2, rmax2, rsum2, v_mask, Sk2, 0, B, H, Sq2, Sk2, dk, scale, D, D, D, D)
+    sec_av = _time_launches(av, iters)
+    exec_av = 4.0 * B * Sq2 * Sk2 * D
+    visited2 = sum(min(Sk2, -(-int(v_mask[b].sum()) // 32) * 32) for b in range(B))
+    issued_av = 4.0 * Sq2 * visited2 * D
+
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
-    tj = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r02_attn_traffic.json")
     if os.path.exists(tj):
         t = json.load(open(tj))
-        if t["shape"] == {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}:
+        if t.get("shape") == {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}:
             traffic = t["traffic_bytes_per_launch"]
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel<128> (cross-modal V<-A, absorbed-projection form: the 128-wide "
-                                       "audio rows are keys and values of all heads)",
-            "achieved": flops / sec / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / 2500.0,
-            "traffic": traffic, "launch_us": sec * 1e6, "flops_per_launch": flops,
-            "executed_flops_per_launch": executed, "executed_tflops": executed / sec / 1e12,
-            "executed_frac": executed / sec / 1e12 / 2500.0,
-            "adjacent_launches_us": {"Q_h Wk_h (2*B*Sq*D*128 flops)": sec_q * 1e6, "context Wv_h^T (same)": sec_o * 1e6},
-            "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}}
+    tf = lambda fl, sec: fl / sec / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": "attn_fwd_kernel<128> = bmhrl_attention_shared128_fwd, the cross-modal V<-A attention (absorbed-projection "
+                  "form: the 128-wide audio rows are keys and values of all heads); flops = those the launch executes",
+        "achieved": tf(exec_va, sec_va), "peak": 2500.0, "unit": "TFLOP/s", "frac": tf(exec_va, sec_va) / 2500.0,
+        "traffic": traffic, "launch_us": sec_va * 1e6, "flops_per_launch": exec_va,
+        "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk, "mask": "padded tails of the synthetic batch"},
+        "mfma_issued_frac": tf(issued_va, sec_va) / 2500.0,
+        "cross_modal_A<-V": {"kernel": "attn_fwd_kernel<256> = bmhrl_attention_fwd (Sq = Ta, Sk = Tv, d_k = 256)",
+                             "launch_us": sec_av * 1e6, "flops_per_launch": exec_av, "achieved": tf(exec_av, sec_av),
+                             "frac": tf(exec_av, sec_av) / 2500.0, "mfma_issued_frac": tf(issued_av, sec_av) / 2500.0},
+        "call_equivalent_V<-A": {"what": "4*B*Sq*Sk*1024 flops of the attention call the launch stands for, over the kernel + "
+                                         "the Q_h Wk_h and context Wv_h^T GEMMs the form adds, timed together (the form also "
+                                         "removes the 2*B*Sk*128*2048-flop K|V projection of the audio rows and its backward)",
+                                 "us": sec_call * 1e6, "flops": call_va, "achieved": tf(call_va, sec_call),
+                                 "frac": tf(call_va, sec_call) / 2500.0},
+    }
 
 
 def cpu_baseline(args):

@@ -37,6 +37,311 @@ struct GemmArgs {
 
 constexpr int BK = 64;
 
+// ---- epilogue, shared by the two main loops.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
+// 4*(lane>>5)) go through LDS (`smem`: SMEM_ELEMS bf16 elements, free once every wave is past the main loop).
+template <int TM, int TN, int SMEM_ELEMS>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], bf16_t* smem, const int b1, const int b2,
+                                              const int m0, const int n0) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) go through
+  // LDS so that every thread then owns 4 consecutive columns of a row: residual / aux / mask loads and the C stores
+  // are 8- or 16-byte, fully coalesced accesses instead of 2- or 4-byte ones at a 32-lane stride.
+  if (p.dbg == 3) { if (acc[0][0][0] == 123.f) p.C[0] = 1.f; return; }
+  // Fast path for the most common output: bf16 only, plain linear epilogue (bias / ReLU / dropout), aligned.  The values
+  // are finished in registers (a lane owns ONE output column, so the bias is a scalar per MFMA tile), staged as bf16
+  // (half the LDS bytes of the generic fp32 staging) and written with 16-byte stores: a wave covers whole 256-byte row
+  // segments.  The projections with K = 128 (audio stream) are bound by exactly this output write.
+  if (p.fast_bf16 && p.splits == 1) {
+    constexpr int SCB = BN + 8;
+    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
+    const float* __restrict__ bp = p.bias ? p.bias + b2 * p.bias_sb2 : nullptr;
+    const uint64_t seedf = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
+    const uint64_t dbase = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
+    auto stage_bf16 = [&](const f32x16& av, const int mi, const int ni) {
+      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
+      const float bias = (bp && n < p.N) ? bp[n] : 0.f;
+      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        float v = av[r] * p.alpha + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seedf, dbase + (uint64_t)(m0 + row) * p.drop_sm + n);
+        sCb[row * SCB + col] = (bf16_t)v;
+      }
+    };
+    stage_bf16(acc[0][0], 0, 0);
+    if constexpr (TN > 1) stage_bf16(acc[0][1], 0, 1);
+    if constexpr (TM > 1) {
+      stage_bf16(acc[1][0], 1, 0);
+      if constexpr (TN > 1) stage_bf16(acc[1][1], 1, 1);
+    }
+    __syncthreads();
+    constexpr int G8 = BM * BN / 8 / 256;          // 16-byte groups per thread
+#pragma unroll
+    for (int i = 0; i < G8; ++i) {
+      const int g = tid + i * 256;
+      const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
+      const int m = m0 + row, n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
+        bf16_t* dst = Cbf + (long)m * p.ldcb + n;
+        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+        else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
+      }
+    }
+    return;
+  }
+  // Same idea for the two softmax epilogues of the attention backward (P recomputation, dS): the row vectors (row max /
+  // 1 / row sum, or delta) are staged in LDS once per tile (the generic path re-loads and re-divides them per 4-column
+  // group), the P tile that dS needs is brought in with 16-byte loads and updated in place, the result leaves as
+  // 16-byte stores.  These GEMMs have K = d_k = 256, i.e. four k-steps: they are all epilogue.
+  if (p.fast_pd && p.splits == 1) {
+    constexpr int SCB = BN + 8;
+    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
+    float* sRV = reinterpret_cast<float*>(smem + BM * SCB);
+    float* sRV2 = sRV + BM;
+    static_assert((BM * SCB) * 2 + 2 * BM * 4 <= SMEM_ELEMS * 2, "softmax epilogue staging must fit");
+    bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
+    const bool prob = p.epilogue == BMHRL_EPI_PROB;
+    const float* __restrict__ rv = p.rowvec + b1 * p.rv_sb1 + b2 * p.rv_sb2;
+    const float* __restrict__ rv2 = prob ? p.rowvec2 + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
+    if (tid < BM) {
+      const int m = min(m0 + tid, p.M - 1);
+      sRV[tid] = rv[m];
+      sRV2[tid] = prob ? __builtin_amdgcn_rcpf(rv2[m]) : 0.f;
+    }
+    constexpr int G8 = BM * BN / 8 / 256;
+    if (!prob) {   // P tile -> LDS
+      const bf16_t* __restrict__ Pg = p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2;
+#pragma unroll
+      for (int i = 0; i < G8; ++i) {
+        const int g = tid + i * 256;
+        const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
+        const int m = m0 + row, n = n0 + c8;
+        bf16x8 v = zero_bf16x8();
+        if (m < p.M && n < p.N) {
+          const bf16_t* src = Pg + (long)m * p.ldaux + n;
+          if (n + 8 <= p.N) v = *reinterpret_cast<const bf16x8*>(src);
+          else for (int j = 0; j < 8 && n + j < p.N; ++j) v[j] = src[j];
+        }
+        *reinterpret_cast<bf16x8*>(sCb + row * SCB + c8) = v;
+      }
+    }
+    __syncthreads();
+    const uint8_t* __restrict__ Mk = (prob && p.mask) ? p.mask + b1 * p.mask_sb1 : nullptr;     // key mask (mask_sm == 0)
+    // a lane's 16 accumulator rows are 4 groups of 4 consecutive rows: the row vectors come in as 16-byte LDS reads, once
+    // per 32-row tile (not once per element and output tile)
+    auto finish = [&](const f32x16& av, const int mi, const int ni, const f32x4 (&r1)[4], const f32x4 (&r2)[4]) {
+      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
+      const bool keep = !Mk || n >= p.N || Mk[n] != 0;
+      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        bf16_t* q = sCb + row * SCB + col;
+        float v;
+        if (prob) {
+          const float x = keep ? av[r] * p.alpha : NEG_MASK;
+          v = __expf(x - r1[r >> 2][r & 3]) * r2[r >> 2][r & 3];
+        } else {
+          v = (float)*q * (av[r] - r1[r >> 2][r & 3]) * p.alpha;
+        }
+        *q = (bf16_t)v;
+      }
+    };
+    auto finish_rows = [&](const int mi) {
+      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+      f32x4 r1[4], r2[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        r1[g] = *reinterpret_cast<const f32x4*>(sRV + row0 + 8 * g);
+        r2[g] = *reinterpret_cast<const f32x4*>(sRV2 + row0 + 8 * g);
+      }
+      finish(acc[mi][0], mi, 0, r1, r2);
+      if constexpr (TN > 1) finish(acc[mi][1], mi, 1, r1, r2);
+    };
+    finish_rows(0);
+    if constexpr (TM > 1) finish_rows(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < G8; ++i) {
+      const int g = tid + i * 256;
+      const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
+      const int m = m0 + row, n = n0 + c8;
+      if (m < p.M && n < p.N) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
+        bf16_t* dst = Cbf + (long)m * p.ldcb + n;
+        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
+        else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
+      }
+    }
+    return;
+  }
+  constexpr int SC = BN + 4;
+  static_assert(BM * SC * 2 <= SMEM_ELEMS, "C tile must fit in the staging buffers");
+  float* sC = reinterpret_cast<float*>(smem);
+  auto stage = [&](const f32x16& av, const int mi, const int ni) {
+    float* base = sC + (wm * 32 * TM + mi * 32 + 4 * h) * SC + wn * 32 * TN + ni * 32 + r32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * SC] = av[r];
+  };
+  stage(acc[0][0], 0, 0);
+  if constexpr (TN > 1) stage(acc[0][1], 0, 1);
+  if constexpr (TM > 1) {
+    stage(acc[1][0], 1, 0);
+    if constexpr (TN > 1) stage(acc[1][1], 1, 1);
+  }
+  __syncthreads();
+
+  float* __restrict__ Cg = p.C ? p.C + b1 * p.c_sb1 + b2 * p.c_sb2 : nullptr;
+  bf16_t* __restrict__ Cbg = p.Cb ? p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 : nullptr;
+  const float* __restrict__ Rg = p.residual ? p.residual + b1 * p.r_sb1 + b2 * p.r_sb2 : nullptr;
+  const uint8_t* __restrict__ Mg = p.mask ? p.mask + b1 * p.mask_sb1 : nullptr;
+  const float* __restrict__ RVg = p.rowvec ? p.rowvec + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
+  const float* __restrict__ RV2g = p.rowvec2 ? p.rowvec2 + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
+  const bf16_t* __restrict__ AUXg = p.aux ? p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2 : nullptr;
+  const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
+  const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
+  const bool first_split = blockIdx.y == 0;
+  const float* __restrict__ biasp = (first_split && p.bias) ? p.bias + b2 * p.bias_sb2 : nullptr;
+  if (!first_split) Rg = nullptr;
+
+  // element-wise part, one variant per epilogue kind (KIND: 0 plain linear, 1 linear with mask / dropout, 2 PROB,
+  // 3 DSCORE, 4 RELU_BWD); x = accumulator, returns the output value
+  auto elem = [&](auto kind, float x, float bias, float res, float aux, float rv, float rv2, int m, int n, bool keep) -> float {
+    constexpr int KIND = decltype(kind)::value;
+    if constexpr (KIND == 0) {
+      x = x * p.alpha + bias;
+      if (p.relu) x = fmaxf(x, 0.f);
+      return x + res;
+    } else if constexpr (KIND == 1) {
+      x = x * p.alpha + bias;
+      if (!keep) x = NEG_MASK;
+      if (p.relu) x = fmaxf(x, 0.f);
+      if (p.dropout_p > 0.f) x *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n);
+      return x + res;
+    } else if constexpr (KIND == 2) {
+      x = x * p.alpha;
+      if (!keep) x = NEG_MASK;
+      return __expf(x - rv) * rv2;
+    } else if constexpr (KIND == 3) {
+      return aux * (x - rv) * p.alpha;
+    } else {
+      return aux > 0.f ? x * p.alpha : 0.f;
+    }
+  };
+
+  constexpr int GROUPS = BM * BN / 4 / 256;
+  // optional column sums of the OUTPUT tile (the bias gradient of the layer whose dY this GEMM produces): a thread
+  // always works on the same 4 columns (256 % (BN/4) == 0), so it keeps a private partial and the 256 / (BN/4) threads
+  // sharing a column group are combined through LDS: one atomic per column per tile
+  float* __restrict__ CSg = p.colsum ? p.colsum + b2 * p.cs_sb2 : nullptr;
+  f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
+  auto run = [&](auto kind) {
+#pragma unroll 4
+    for (int i = 0; i < GROUPS; ++i) {
+      const int g = tid + i * 256;
+      const int row = g / (BN / 4), c4 = (g % (BN / 4)) * 4;
+      const int m = m0 + row, n = n0 + c4;
+      if (m < p.M && n < p.N) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * SC + c4);
+        const float rv = RVg ? RVg[m] : 0.f;
+        const float rv2 = RV2g ? __builtin_amdgcn_rcpf(RV2g[m]) : 1.f;      // 1 ulp reciprocal: P is rounded to bf16 anyway
+        if (p.vec_ok && n + 4 <= p.N) {
+          f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = {0.f, 0.f, 0.f, 0.f}, x4 = {0.f, 0.f, 0.f, 0.f};
+          if (biasp) b4 = *reinterpret_cast<const f32x4*>(biasp + n);
+          if (Rg) r4 = *reinterpret_cast<const f32x4*>(Rg + (long)m * p.ldr + n);
+          if (AUXg) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(AUXg + (long)m * p.ldaux + n);
+            x4[0] = (float)t[0]; x4[1] = (float)t[1]; x4[2] = (float)t[2]; x4[3] = (float)t[3];
+          }
+          uint32_t keep4 = 0x01010101u;        // mask bytes of the 4 columns (one 4-byte load when aligned)
+          if constexpr (decltype(kind)::value == 1 || decltype(kind)::value == 2) {
+            if (Mg) {
+              const uint8_t* mp = Mg + (long)m * p.mask_sm + n;
+              if (((uintptr_t)mp & 3) == 0) keep4 = *reinterpret_cast<const uint32_t*>(mp);
+              else keep4 = (uint32_t)mp[0] | ((uint32_t)mp[1] << 8) | ((uint32_t)mp[2] << 16) | ((uint32_t)mp[3] << 24);
+            }
+          }
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j, ((keep4 >> (8 * j)) & 0xffu) != 0);
+          cs4 += o;
+          if (Cg) {
+            float* dst = Cg + (long)m * p.ldc + n;
+            if (p.splits > 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) atomicAdd(dst + j, o[j]);
+            } else {
+              if (p.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+              *reinterpret_cast<f32x4*>(dst) = o;
+            }
+          }
+          if (Cbg) {
+            bf16x4 ob;
+            ob[0] = (bf16_t)o[0]; ob[1] = (bf16_t)o[1]; ob[2] = (bf16_t)o[2]; ob[3] = (bf16_t)o[3];
+            *reinterpret_cast<bf16x4*>(Cbg + (long)m * p.ldcb + n) = ob;
+          }
+        } else {   // ragged right edge or unaligned operands: scalar accesses
+          for (int j = 0; j < 4 && n + j < p.N; ++j) {
+            const float b = biasp ? biasp[n + j] : 0.f;
+            const float r = Rg ? Rg[(long)m * p.ldr + n + j] : 0.f;
+            const float ax = AUXg ? (float)AUXg[(long)m * p.ldaux + n + j] : 0.f;
+            const bool keep = !Mg || Mg[(long)m * p.mask_sm + n + j] != 0;
+            const float o = elem(kind, a4[j], b, r, ax, rv, rv2, m, n + j, keep);
+            cs4[j] += o;
+            if (Cg) {
+              float* dst = Cg + (long)m * p.ldc + n + j;
+              if (p.splits > 1) atomicAdd(dst, o);
+              else *dst = p.accumulate ? *dst + o : o;
+            }
+            if (Cbg) Cbg[(long)m * p.ldcb + n + j] = (bf16_t)o;
+          }
+        }
+      }
+    }
+  };
+  if (p.splits > 1) {
+    // split-K partial sums: lane l adds column l of a row, so one wave instruction covers 256 contiguous bytes (the
+    // shape float atomics run at full rate with); bias / residual are added by the first split only.
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int row = idx / BN, col = idx % BN;
+      const int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) {
+        float x = sC[row * SC + col] * p.alpha;
+        if (biasp) x += biasp[n];
+        if (Rg) x += Rg[(long)m * p.ldr + n];
+        atomicAdd(Cg + (long)m * p.ldc + n, x);
+      }
+    }
+    return;
+  }
+  if (p.epilogue == BMHRL_EPI_LINEAR) {
+    if (!Mg && p.dropout_p == 0.f) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+  } else if (p.epilogue == BMHRL_EPI_PROB) run(std::integral_constant<int, 2>{});
+  else if (p.epilogue == BMHRL_EPI_DSCORE) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, 4>{});
+  if (CSg) {
+    constexpr int CG = BN / 4, SHARE = 256 / CG;        // column groups per tile, threads per group
+    __syncthreads();                                    // everyone is done reading the staged accumulators
+    *reinterpret_cast<f32x4*>(sC + (tid / CG) * BN + (tid % CG) * 4) = cs4;
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < SHARE; ++k) t += sC[k * BN + tid];
+      atomicAdd(CSg + n0 + tid, t);
+    }
+  }
+}
+
 template <int TM, int TN, bool AT, bool BT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -219,300 +524,251 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
   }
 
-  // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) go through
-  // LDS so that every thread then owns 4 consecutive columns of a row: residual / aux / mask loads and the C stores
-  // are 8- or 16-byte, fully coalesced accesses instead of 2- or 4-byte ones at a 32-lane stride.
-  if (p.dbg == 3) { if (acc[0][0][0] == 123.f) p.C[0] = 1.f; return; }
-  // Fast path for the most common output: bf16 only, plain linear epilogue (bias / ReLU / dropout), aligned.  The values
-  // are finished in registers (a lane owns ONE output column, so the bias is a scalar per MFMA tile), staged as bf16
-  // (half the LDS bytes of the generic fp32 staging) and written with 16-byte stores: a wave covers whole 256-byte row
-  // segments.  The projections with K = 128 (audio stream) are bound by exactly this output write.
-  if (p.fast_bf16 && p.splits == 1) {
-    constexpr int SCB = BN + 8;
-    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
-    const float* __restrict__ bp = p.bias ? p.bias + b2 * p.bias_sb2 : nullptr;
-    const uint64_t seedf = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
-    const uint64_t dbase = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
-    auto stage_bf16 = [&](const f32x16& av, const int mi, const int ni) {
-      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
-      const float bias = (bp && n < p.N) ? bp[n] : 0.f;
-      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        float v = av[r] * p.alpha + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seedf, dbase + (uint64_t)(m0 + row) * p.drop_sm + n);
-        sCb[row * SCB + col] = (bf16_t)v;
-      }
-    };
-    stage_bf16(acc[0][0], 0, 0);
-    if constexpr (TN > 1) stage_bf16(acc[0][1], 0, 1);
-    if constexpr (TM > 1) {
-      stage_bf16(acc[1][0], 1, 0);
-      if constexpr (TN > 1) stage_bf16(acc[1][1], 1, 1);
-    }
-    __syncthreads();
-    constexpr int G8 = BM * BN / 8 / 256;          // 16-byte groups per thread
-#pragma unroll
-    for (int i = 0; i < G8; ++i) {
-      const int g = tid + i * 256;
-      const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
-      const int m = m0 + row, n = n0 + c8;
-      if (m < p.M && n < p.N) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
-        bf16_t* dst = Cbf + (long)m * p.ldcb + n;
-        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
-        else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
-      }
-    }
-    return;
+  gemm_epilogue<TM, TN, 2 * (A_ELEMS + B_ELEMS)>(p, acc, smem, b1, b2, m0, n0);    // (every step ends in a barrier)
+}
+
+
+// ---- Main loop on direct-to-LDS loads (every reduction whose k range is a multiple of 64: all the large projections).
+// global_load_lds moves 1 KiB per wave instruction straight into the tile image (no staging registers, no ds_write); the
+// image is lane-linear, so bank conflicts are avoided by XOR-swizzling the SOURCE chunk and reading through the same XOR:
+//   k-contiguous operand   [rows][64 k], 128-byte rows : 16-byte chunk ^= (row >> 1) & 7   (ds_read_b128: the 16 rows of a
+//                                                        lane group fall on 16 different slots of the 256-byte bank row)
+//   transposed operand     [64 k][R],  R*2-byte rows   : chunk ^= (k & 3) << 2 (R = 128) or ((k >> 1) & 1) << 2 (R = 64):
+//                                                        the 4 k-rows of a ds_read_b64_tr_b16 block sit on 4 bank quarters
+// Two stages; a step issues the loads of tile t+1, multiplies tile t and ends in vmcnt(0) + barrier.  The fragment reads
+// are inline asm with counted lgkmcnt waits: the compiler would put a vmcnt(0) in front of every LDS read it can see while
+// a direct-to-LDS load is in flight (it cannot tell the stages apart), serialising load and multiply; all LDS addresses
+// are one VGPR per operand fragment row + immediates (the k-loop is unrolled over the two stages).
+template <int N> struct IC { static constexpr int value = N; };
+template <int I, int N, class F>
+__device__ __forceinline__ void gsfor(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    gsfor<I + 1, N>(f);
   }
-  // Same idea for the two softmax epilogues of the attention backward (P recomputation, dS): the row vectors (row max /
-  // 1 / row sum, or delta) are staged in LDS once per tile (the generic path re-loads and re-divides them per 4-column
-  // group), the P tile that dS needs is brought in with 16-byte loads and updated in place, the result leaves as
-  // 16-byte stores.  These GEMMs have K = d_k = 256, i.e. four k-steps: they are all epilogue.
-  if (p.fast_pd && p.splits == 1) {
-    constexpr int SCB = BN + 8;
-    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
-    float* sRV = reinterpret_cast<float*>(smem + BM * SCB);
-    float* sRV2 = sRV + BM;
-    static_assert((BM * SCB) * 2 + 2 * BM * 4 <= 2 * (A_ELEMS + B_ELEMS) * 2, "softmax epilogue staging must fit");
-    bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
-    const bool prob = p.epilogue == BMHRL_EPI_PROB;
-    const float* __restrict__ rv = p.rowvec + b1 * p.rv_sb1 + b2 * p.rv_sb2;
-    const float* __restrict__ rv2 = prob ? p.rowvec2 + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
-    if (tid < BM) {
-      const int m = min(m0 + tid, p.M - 1);
-      sRV[tid] = rv[m];
-      sRV2[tid] = prob ? __builtin_amdgcn_rcpf(rv2[m]) : 0.f;
+}
+template <int IMM>
+__device__ __forceinline__ void gemm_glds16(const char* src, char* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst, 16, IMM, 0);
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 gemm_lds128(unsigned addr) {     // (asm: see the header of the kernel below)
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x4 gemm_ldstr(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+template <int TM, int TN, bool AT, bool BT, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int EPI_ELEMS = BM * (BN + 4) * 2;                       // fp32 C staging of the epilogue, in bf16 elements
+  constexpr int SMEM_ELEMS = (NS * STAGE_BYTES / 2) > EPI_ELEMS ? (NS * STAGE_BYTES / 2) : EPI_ELEMS;
+
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_ELEMS];
+  char* const sbase = reinterpret_cast<char*>(smem);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sbase;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int bz = blockIdx.z, b1 = bz / p.batch2, b2 = bz % p.batch2;
+  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A + b1 * p.a_sb1 + b2 * p.a_sb2);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B + b1 * p.b_sb1 + b2 * p.b_sb2);
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const int k_begin = blockIdx.y * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin) / BK;                             // whole tiles only (host-checked)
+  if (nk <= 0) return;
+
+  // ---- staging: per-lane byte offsets from the operand base, fixed for the launch (rows / columns past the matrix edge
+  // are clamped to valid memory: they only feed outputs that are never stored); the uniform base advances by one k-tile
+  constexpr int PA = A_BYTES / 1024 / 4, PB = B_BYTES / 1024 / 4;     // 1 KiB pieces per wave and operand (4 / 2)
+  unsigned a_off[PA], b_off[PB];
+  auto piece_off = [&](const bool trans, const int R, const int i, const int r0, const int rmax, const int rmax8, const long ld) {
+    if (!trans) {                       // [R rows][64 k]: 8 rows per piece
+      const int row = wave * (R / 4) + 8 * i + (lane >> 3), pc = lane & 7;
+      const int sc = pc ^ ((row >> 1) & 7);
+      return (unsigned)((long)min(r0 + row, rmax - 1) * ld * 2 + sc * 16);
     }
-    constexpr int G8 = BM * BN / 8 / 256;
-    if (!prob) {   // P tile -> LDS
-      const bf16_t* __restrict__ Pg = p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2;
-#pragma unroll
-      for (int i = 0; i < G8; ++i) {
-        const int g = tid + i * 256;
-        const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
-        const int m = m0 + row, n = n0 + c8;
-        bf16x8 v = zero_bf16x8();
-        if (m < p.M && n < p.N) {
-          const bf16_t* src = Pg + (long)m * p.ldaux + n;
-          if (n + 8 <= p.N) v = *reinterpret_cast<const bf16x8*>(src);
-          else for (int j = 0; j < 8 && n + j < p.N; ++j) v[j] = src[j];
-        }
-        *reinterpret_cast<bf16x8*>(sCb + row * SCB + c8) = v;
-      }
-    }
-    __syncthreads();
-    const uint8_t* __restrict__ Mk = (prob && p.mask) ? p.mask + b1 * p.mask_sb1 : nullptr;     // key mask (mask_sm == 0)
-    // a lane's 16 accumulator rows are 4 groups of 4 consecutive rows: the row vectors come in as 16-byte LDS reads, once
-    // per 32-row tile (not once per element and output tile)
-    auto finish = [&](const f32x16& av, const int mi, const int ni, const f32x4 (&r1)[4], const f32x4 (&r2)[4]) {
-      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
-      const bool keep = !Mk || n >= p.N || Mk[n] != 0;
-      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        bf16_t* q = sCb + row * SCB + col;
-        float v;
-        if (prob) {
-          const float x = keep ? av[r] * p.alpha : NEG_MASK;
-          v = __expf(x - r1[r >> 2][r & 3]) * r2[r >> 2][r & 3];
-        } else {
-          v = (float)*q * (av[r] - r1[r >> 2][r & 3]) * p.alpha;
-        }
-        *q = (bf16_t)v;
-      }
-    };
-    auto finish_rows = [&](const int mi) {
-      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
-      f32x4 r1[4], r2[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        r1[g] = *reinterpret_cast<const f32x4*>(sRV + row0 + 8 * g);
-        r2[g] = *reinterpret_cast<const f32x4*>(sRV2 + row0 + 8 * g);
-      }
-      finish(acc[mi][0], mi, 0, r1, r2);
-      if constexpr (TN > 1) finish(acc[mi][1], mi, 1, r1, r2);
-    };
-    finish_rows(0);
-    if constexpr (TM > 1) finish_rows(1);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < G8; ++i) {
-      const int g = tid + i * 256;
-      const int row = g / (BN / 8), c8 = (g % (BN / 8)) * 8;
-      const int m = m0 + row, n = n0 + c8;
-      if (m < p.M && n < p.N) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
-        bf16_t* dst = Cbf + (long)m * p.ldcb + n;
-        if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
-        else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
-      }
-    }
-    return;
-  }
-  constexpr int SC = BN + 4;
-  static_assert(BM * SC * 2 <= 2 * (A_ELEMS + B_ELEMS), "C tile must fit in the staging buffers");
-  float* sC = reinterpret_cast<float*>(smem);
-  auto stage = [&](const f32x16& av, const int mi, const int ni) {
-    float* base = sC + (wm * 32 * TM + mi * 32 + 4 * h) * SC + wn * 32 * TN + ni * 32 + r32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * SC] = av[r];
+    const int cpr = R / 8, rpp = 64 / cpr;                             // chunks per row, k-rows per piece
+    const int krow = wave * 16 + rpp * i + lane / cpr, pc = lane % cpr;
+    const int sc = pc ^ (R == 128 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2));
+    return (unsigned)((long)krow * ld * 2 + (long)min(r0 + sc * 8, rmax8 - 8) * 2);
   };
-  stage(acc[0][0], 0, 0);
-  if constexpr (TN > 1) stage(acc[0][1], 0, 1);
-  if constexpr (TM > 1) {
-    stage(acc[1][0], 1, 0);
-    if constexpr (TN > 1) stage(acc[1][1], 1, 1);
-  }
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PA; ++i) a_off[i] = piece_off(AT, BM, i, m0, p.M, M8, p.lda);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) b_off[i] = piece_off(BT, BN, i, n0, p.N, N8, p.ldb);
+  const long a_step = AT ? (long)BK * p.lda * 2 : (long)BK * 2, b_step = BT ? (long)BK * p.ldb * 2 : (long)BK * 2;
+  const char* const a_k0 = Ag + (AT ? (long)k_begin * p.lda * 2 : (long)k_begin * 2);
+  const char* const b_k0 = Bg + (BT ? (long)k_begin * p.ldb * 2 : (long)k_begin * 2);
+  // LDS destination of this wave's pieces inside a stage: consecutive 1 KiB pieces (wave w: pieces [w*P, w*P + P))
+  char* const a_dst = sbase + wave * PA * 1024;
+  char* const b_dst = sbase + A_BYTES + wave * PB * 1024;
+  auto stage = [&](auto st_, const int t) {        // tile t of this block's reduction -> stage ST
+    constexpr int ST = decltype(st_)::value;
+    // uniform (SGPR) base + the lane's fixed 32-bit offset: the readfirstlane keeps the sum in scalar registers (the
+    // compiler otherwise re-associates it into two 64-bit vector adds per load)
+    auto sgpr_ptr = [](const char* q) {
+      const uint64_t u = reinterpret_cast<uint64_t>(q);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+      return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* ab = sgpr_ptr(a_k0 + (long)t * a_step);
+    const char* bb = sgpr_ptr(b_k0 + (long)t * b_step);
+    gsfor<0, PA>([&](auto i) {
+      constexpr int I = decltype(i)::value;
+      unsigned o = a_off[I];
+      asm volatile("" : "+v"(o));
+      gemm_glds16<0>(ab + o, a_dst + ST * STAGE_BYTES + I * 1024);
+    });
+    gsfor<0, PB>([&](auto i) {
+      constexpr int I = decltype(i)::value;
+      unsigned o = b_off[I];
+      asm volatile("" : "+v"(o));
+      gemm_glds16<0>(bb + o, b_dst + ST * STAGE_BYTES + I * 1024);
+    });
+  };
 
-  float* __restrict__ Cg = p.C ? p.C + b1 * p.c_sb1 + b2 * p.c_sb2 : nullptr;
-  bf16_t* __restrict__ Cbg = p.Cb ? p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 : nullptr;
-  const float* __restrict__ Rg = p.residual ? p.residual + b1 * p.r_sb1 + b2 * p.r_sb2 : nullptr;
-  const uint8_t* __restrict__ Mg = p.mask ? p.mask + b1 * p.mask_sb1 : nullptr;
-  const float* __restrict__ RVg = p.rowvec ? p.rowvec + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
-  const float* __restrict__ RV2g = p.rowvec2 ? p.rowvec2 + b1 * p.rv_sb1 + b2 * p.rv_sb2 : nullptr;
-  const bf16_t* __restrict__ AUXg = p.aux ? p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2 : nullptr;
-  const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
-  const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
-  const bool first_split = blockIdx.y == 0;
-  const float* __restrict__ biasp = (first_split && p.bias) ? p.bias + b2 * p.bias_sb2 : nullptr;
-  if (!first_split) Rg = nullptr;
-
-  // element-wise part, one variant per epilogue kind (KIND: 0 plain linear, 1 linear with mask / dropout, 2 PROB,
-  // 3 DSCORE, 4 RELU_BWD); x = accumulator, returns the output value
-  auto elem = [&](auto kind, float x, float bias, float res, float aux, float rv, float rv2, int m, int n, bool keep) -> float {
-    constexpr int KIND = decltype(kind)::value;
-    if constexpr (KIND == 0) {
-      x = x * p.alpha + bias;
-      if (p.relu) x = fmaxf(x, 0.f);
-      return x + res;
-    } else if constexpr (KIND == 1) {
-      x = x * p.alpha + bias;
-      if (!keep) x = NEG_MASK;
-      if (p.relu) x = fmaxf(x, 0.f);
-      if (p.dropout_p > 0.f) x *= dropout_scale(p.dropout_p, seed, drop_base + (uint64_t)m * p.drop_sm + n);
-      return x + res;
-    } else if constexpr (KIND == 2) {
-      x = x * p.alpha;
-      if (!keep) x = NEG_MASK;
-      return __expf(x - rv) * rv2;
-    } else if constexpr (KIND == 3) {
-      return aux * (x - rv) * p.alpha;
+  // ---- fragment addresses, one set per stage (the k-steps / fragment rows are 16-bit immediates)
+  //   k-contiguous: row = wX*32*T + 32*i + r32, chunk (2 ks + h) ^ ((r32 >> 1) & 7): one address per ks
+  //   transposed  : k-row 16 ks + 8 h + q4 (+4), chunk (wX*4*T + 4 i + 2 g1 + (p4 >> 1)) ^ swizzle(q4): one address per i
+  constexpr int NA = AT ? TM : 4, NB = BT ? TN : 4;
+  unsigned a_addr[NS][NA], b_addr[NS][NB];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const unsigned sb = lds0 + st * STAGE_BYTES;
+    if constexpr (!AT) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a_addr[st][ks] = sb + (wm * 32 * TM + r32) * 128 + (((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4);
     } else {
-      return aux > 0.f ? x * p.alpha : 0.f;
+      constexpr int RB = BM * 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int c = wm * 4 * TM + 4 * i + 2 * g1 + (p4 >> 1);
+        const int sw = BM == 128 ? (q4 << 2) : (((q4 >> 1) & 1) << 2);
+        a_addr[st][i] = sb + (8 * h + q4) * RB + ((c ^ sw) << 4) + ((p4 & 1) << 3);
+      }
     }
+    if constexpr (!BT) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b_addr[st][ks] = sb + A_BYTES + (wn * 32 * TN + r32) * 128 + (((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4);
+    } else {
+      constexpr int RB = BN * 2;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int c = wn * 4 * TN + 4 * i + 2 * g1 + (p4 >> 1);
+        const int sw = BN == 128 ? (q4 << 2) : (((q4 >> 1) & 1) << 2);
+        b_addr[st][i] = sb + A_BYTES + (8 * h + q4) * RB + ((c ^ sw) << 4) + ((p4 & 1) << 3);
+      }
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one k-tile out of stage ST: the fragment reads run one k-step ahead of the MFMAs (LDS returns in order: "at most N
+  // outstanding" = everything older has arrived; the counter has 4 bits, so no more than two k-steps are in flight)
+  constexpr int RA = AT ? 2 : 1, RBn = BT ? 2 : 1;            // LDS reads per fragment
+  constexpr int PER_KS = TM * RA + TN * RBn;                  // reads per k-step (<= 8)
+  auto compute = [&](auto st_) {
+    constexpr int ST = decltype(st_)::value;
+    bf16x8 af[4][TM], bfr[4][TN];
+    auto read_ks = [&](auto ks_) {
+      constexpr int KS = decltype(ks_)::value;
+      gsfor<0, TM>([&](auto i_) {
+        constexpr int I = decltype(i_)::value;
+        if constexpr (!AT) {
+          af[KS][I] = gemm_lds128<I * 32 * 128>(a_addr[ST][KS]);
+        } else {
+          constexpr int RB = BM * 2;
+          af[KS][I] = join8(gemm_ldstr<KS * 16 * RB>(a_addr[ST][I]), gemm_ldstr<(KS * 16 + 4) * RB>(a_addr[ST][I]));
+        }
+      });
+      gsfor<0, TN>([&](auto i_) {
+        constexpr int I = decltype(i_)::value;
+        if constexpr (!BT) {
+          bfr[KS][I] = gemm_lds128<I * 32 * 128>(b_addr[ST][KS]);
+        } else {
+          constexpr int RB = BN * 2;
+          bfr[KS][I] = join8(gemm_ldstr<KS * 16 * RB>(b_addr[ST][I]), gemm_ldstr<(KS * 16 + 4) * RB>(b_addr[ST][I]));
+        }
+      });
+    };
+    read_ks(IC<0>{});
+    read_ks(IC<1>{});
+    gsfor<0, 4>([&](auto ks_) {
+      constexpr int KS = decltype(ks_)::value;
+      constexpr int LEFT = KS < 3 ? PER_KS : 0;                // the reads of the next k-step may still be in flight
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8& a0 = af[KS][0];
+      bf16x8& b0 = bfr[KS][0];
+      bf16x8& a1 = af[KS][TM - 1];
+      bf16x8& b1r = bfr[KS][TN - 1];
+      if constexpr (TM == 2 && TN == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1r) : "n"(LEFT));
+      else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0), "+v"(b0) : "n"(LEFT));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[KS][mi], bfr[KS][ni], acc[mi][ni], 0, 0, 0);
+      if constexpr (KS + 2 < 4) read_ks(IC<KS + 2>{});
+    });
   };
 
-  constexpr int GROUPS = BM * BN / 4 / 256;
-  // optional column sums of the OUTPUT tile (the bias gradient of the layer whose dY this GEMM produces): a thread
-  // always works on the same 4 columns (256 % (BN/4) == 0), so it keeps a private partial and the 256 / (BN/4) threads
-  // sharing a column group are combined through LDS: one atomic per column per tile
-  float* __restrict__ CSg = p.colsum ? p.colsum + b2 * p.cs_sb2 : nullptr;
-  f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
-  auto run = [&](auto kind) {
-#pragma unroll 4
-    for (int i = 0; i < GROUPS; ++i) {
-      const int g = tid + i * 256;
-      const int row = g / (BN / 4), c4 = (g % (BN / 4)) * 4;
-      const int m = m0 + row, n = n0 + c4;
-      if (m < p.M && n < p.N) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sC + row * SC + c4);
-        const float rv = RVg ? RVg[m] : 0.f;
-        const float rv2 = RV2g ? __builtin_amdgcn_rcpf(RV2g[m]) : 1.f;      // 1 ulp reciprocal: P is rounded to bf16 anyway
-        if (p.vec_ok && n + 4 <= p.N) {
-          f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = {0.f, 0.f, 0.f, 0.f}, x4 = {0.f, 0.f, 0.f, 0.f};
-          if (biasp) b4 = *reinterpret_cast<const f32x4*>(biasp + n);
-          if (Rg) r4 = *reinterpret_cast<const f32x4*>(Rg + (long)m * p.ldr + n);
-          if (AUXg) {
-            const bf16x4 t = *reinterpret_cast<const bf16x4*>(AUXg + (long)m * p.ldaux + n);
-            x4[0] = (float)t[0]; x4[1] = (float)t[1]; x4[2] = (float)t[2]; x4[3] = (float)t[3];
-          }
-          uint32_t keep4 = 0x01010101u;        // mask bytes of the 4 columns (one 4-byte load when aligned)
-          if constexpr (decltype(kind)::value == 1 || decltype(kind)::value == 2) {
-            if (Mg) {
-              const uint8_t* mp = Mg + (long)m * p.mask_sm + n;
-              if (((uintptr_t)mp & 3) == 0) keep4 = *reinterpret_cast<const uint32_t*>(mp);
-              else keep4 = (uint32_t)mp[0] | ((uint32_t)mp[1] << 8) | ((uint32_t)mp[2] << 16) | ((uint32_t)mp[3] << 24);
-            }
-          }
-          f32x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j, ((keep4 >> (8 * j)) & 0xffu) != 0);
-          cs4 += o;
-          if (Cg) {
-            float* dst = Cg + (long)m * p.ldc + n;
-            if (p.splits > 1) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) atomicAdd(dst + j, o[j]);
-            } else {
-              if (p.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
-              *reinterpret_cast<f32x4*>(dst) = o;
-            }
-          }
-          if (Cbg) {
-            bf16x4 ob;
-            ob[0] = (bf16_t)o[0]; ob[1] = (bf16_t)o[1]; ob[2] = (bf16_t)o[2]; ob[3] = (bf16_t)o[3];
-            *reinterpret_cast<bf16x4*>(Cbg + (long)m * p.ldcb + n) = ob;
-          }
-        } else {   // ragged right edge or unaligned operands: scalar accesses
-          for (int j = 0; j < 4 && n + j < p.N; ++j) {
-            const float b = biasp ? biasp[n + j] : 0.f;
-            const float r = Rg ? Rg[(long)m * p.ldr + n + j] : 0.f;
-            const float ax = AUXg ? (float)AUXg[(long)m * p.ldaux + n + j] : 0.f;
-            const bool keep = !Mg || Mg[(long)m * p.mask_sm + n + j] != 0;
-            const float o = elem(kind, a4[j], b, r, ax, rv, rv2, m, n + j, keep);
-            cs4[j] += o;
-            if (Cg) {
-              float* dst = Cg + (long)m * p.ldc + n + j;
-              if (p.splits > 1) atomicAdd(dst, o);
-              else *dst = p.accumulate ? *dst + o : o;
-            }
-            if (Cbg) Cbg[(long)m * p.ldcb + n + j] = (bf16_t)o;
-          }
-        }
-      }
+  // NS stages: tiles t+1 .. t+NS-2 stay in flight across the barrier of step t (counted vmcnt: a wave's loads complete in
+  // order, so "at most (NS-2) tiles' worth outstanding" = tile t+1 has landed).  Two stages suit shapes with >= 2
+  // workgroups per CU (the other workgroup covers the wait); with one workgroup per CU -- the 4096 x 1024 projections: 256
+  // tiles -- a load issued at the top of a 0.25 us step would be awaited at its end, and NS = 4 hides the latency instead.
+  constexpr int PT = PA + PB;                                   // this wave's pieces per tile
+  auto step = [&](auto st_, const int t) {                      // multiply tile t (stage ST = t % NS)
+    constexpr int ST = decltype(st_)::value;
+    constexpr int NXT = (ST + NS - 1) % NS;                     // the stage read in step t-1
+    const bool more = t + NS - 1 < nk;
+    if (more) stage(IC<NXT>{}, t + NS - 1);
+    compute(st_);
+    if (t + 1 < nk) {
+      if (more && NS > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the tail drains completely: simple and at most NS-2 steps)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
   };
-  if (p.splits > 1) {
-    // split-K partial sums: lane l adds column l of a row, so one wave instruction covers 256 contiguous bytes (the
-    // shape float atomics run at full rate with); bias / residual are added by the first split only.
-    for (int idx = tid; idx < BM * BN; idx += 256) {
-      const int row = idx / BN, col = idx % BN;
-      const int m = m0 + row, n = n0 + col;
-      if (m < p.M && n < p.N) {
-        float x = sC[row * SC + col] * p.alpha;
-        if (biasp) x += biasp[n];
-        if (Rg) x += Rg[(long)m * p.ldr + n];
-        atomicAdd(Cg + (long)m * p.ldc + n, x);
-      }
-    }
-    return;
+  gsfor<0, NS - 1>([&](auto i_) {
+    if (decltype(i_)::value < nk) stage(i_, decltype(i_)::value);
+  });
+  if (NS > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PT) : "memory");   // tile 0 (conservative when nk < NS-1: see below)
+  if (NS == 2 || nk < NS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int t0 = 0; t0 < nk; t0 += NS) {
+    gsfor<0, NS>([&](auto i_) {
+      if (t0 + decltype(i_)::value < nk) step(i_, t0 + decltype(i_)::value);
+    });
   }
-  if (p.epilogue == BMHRL_EPI_LINEAR) {
-    if (!Mg && p.dropout_p == 0.f) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
-  } else if (p.epilogue == BMHRL_EPI_PROB) run(std::integral_constant<int, 2>{});
-  else if (p.epilogue == BMHRL_EPI_DSCORE) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, 4>{});
-  if (CSg) {
-    constexpr int CG = BN / 4, SHARE = 256 / CG;        // column groups per tile, threads per group
-    __syncthreads();                                    // everyone is done reading the staged accumulators
-    *reinterpret_cast<f32x4*>(sC + (tid / CG) * BN + (tid % CG) * 4) = cs4;
-    __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < SHARE; ++k) t += sC[k * BN + tid];
-      atomicAdd(CSg + n0 + tid, t);
-    }
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();             // every wave is done with the stages: the epilogue reuses them
+  asm volatile("" ::: "memory");
+  gemm_epilogue<TM, TN, SMEM_ELEMS>(p, acc, smem, b1, b2, m0, n0);
 }
 
 template <int TM, int TN>
@@ -526,6 +782,31 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
   const int ktiles = (a.K + BK - 1) / BK;
   p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
   dim3 grid(p.tiles_m * tiles_n, splits, batch), block(256);
+  // direct-to-LDS main loop: whole k-tiles only (no zero fill of a ragged reduction tail) and 32-bit lane offsets
+  static const int no_glds = getenv("BMHRL_GEMM_NOGLDS") ? atoi(getenv("BMHRL_GEMM_NOGLDS")) : 0;       // (tuning aid: A/B)
+  const long a_span = (a_trans ? 64 : (long)a.M) * a.lda * 2, b_span = (b_trans ? 64 : (long)a.N) * a.ldb * 2;
+  const bool glds = !no_glds && a.K % BK == 0 && a_span < (1l << 31) && b_span < (1l << 31) && a.M >= 8 && a.N >= 8;
+  if (glds) {
+    // stages: 2 for the 128 x 128 tiles (two workgroups per CU cover each other's waits; four stages at one workgroup per
+    // CU measured equal or slower on every shape of the step: these sizes are bound by the ~70 GB/s a CU gets from L2 into
+    // LDS, not by exposed latency); 4 for the 64 x 64 tiles when the grid gives a CU at most two of them (16 KiB stages:
+    // a step is only 4 MFMAs per wave, the loads run three steps ahead -- 1024 x 1024 x 4096 dW 34 -> 21 us; with more
+    // workgroups per CU, or a K split, the smaller footprint of two stages wins: 3072 x 1024 x 4096 dW 42 vs 49 us)
+    static const int force_ns = getenv("BMHRL_GEMM_STAGES") ? atoi(getenv("BMHRL_GEMM_STAGES")) : 0;   // (tuning aid)
+    const long blocks = (long)p.tiles_m * tiles_n * batch;
+    const bool deep = force_ns ? force_ns == 4 : (TM == 1 && splits == 1 && blocks <= 448);
+#define BMHRL_GLDS(AT_, BT_)                                                                                    \
+    do {                                                                                                          \
+      if (TM == 1 && deep) hipLaunchKernelGGL((gemm_glds_kernel<TM, TN, AT_, BT_, TM == 1 ? 4 : 2>), grid, block, 0, s, p); \
+      else hipLaunchKernelGGL((gemm_glds_kernel<TM, TN, AT_, BT_, 2>), grid, block, 0, s, p);                   \
+    } while (0)
+    if (!a_trans && !b_trans) BMHRL_GLDS(false, false);
+    else if (!a_trans && b_trans) BMHRL_GLDS(false, true);
+    else if (a_trans && !b_trans) BMHRL_GLDS(true, false);
+    else BMHRL_GLDS(true, true);
+#undef BMHRL_GLDS
+    return hipGetLastError();
+  }
   if (!a_trans && !b_trans) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, p);
   else if (!a_trans && b_trans) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, p);
   else if (a_trans && !b_trans) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, p);

@@ -5,6 +5,7 @@ cd "$(dirname "$0")/../.."
 python -m bmhrl_amd.build > /dev/null
 HIPCC=/opt/rocm/bin/hipcc
 $HIPCC -O2 -std=c++17 tests/kbench/attn_bench.cpp -o tests/kbench/attn_bench -Lbmhrl_amd/csrc -lbmhrl_hip -Wl,-rpath,'$ORIGIN/../../bmhrl_amd/csrc' 2>&1 | grep -v hip-link || true
+$HIPCC -O2 -std=c++17 tests/kbench/gemm_bench.cpp -o tests/kbench/gemm_bench -Lbmhrl_amd/csrc -lbmhrl_hip -Wl,-rpath,'$ORIGIN/../../bmhrl_amd/csrc' 2>&1 | grep -v hip-link || true
 if [ "$1" = "trace" ]; then   # the attention kernels with cycle stamps (-DBMHRL_ATTN_TRACE), linked statically into a second binary
   mkdir -p tests/kbench/build
   F="--offload-arch=gfx950 -O3 -std=c++17 -Wno-comment -DBMHRL_ATTN_TRACE -mllvm -amdgpu-codegenprepare-break-large-phis=false"
