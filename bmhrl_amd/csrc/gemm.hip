@@ -647,33 +647,29 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   //   k-contiguous: row = wX*32*T + 32*i + r32, chunk (2 ks + h) ^ ((r32 >> 1) & 7): one address per ks
   //   transposed  : k-row 16 ks + 8 h + q4 (+4), chunk (wX*4*T + 4 i + 2 g1 + (p4 >> 1)) ^ swizzle(q4): one address per i
   constexpr int NA = AT ? TM : 4, NB = BT ? TN : 4;
-  unsigned a_addr[NS][NA], b_addr[NS][NB];
+  unsigned a_addr0[NA], b_addr0[NB];              // stage 0; a step adds its stage's (uniform) byte offset
+  if constexpr (!AT) {
 #pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    const unsigned sb = lds0 + st * STAGE_BYTES;
-    if constexpr (!AT) {
+    for (int ks = 0; ks < 4; ++ks) a_addr0[ks] = lds0 + (wm * 32 * TM + r32) * 128 + (((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4);
+  } else {
+    constexpr int RB = BM * 2;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a_addr[st][ks] = sb + (wm * 32 * TM + r32) * 128 + (((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4);
-    } else {
-      constexpr int RB = BM * 2;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int c = wm * 4 * TM + 4 * i + 2 * g1 + (p4 >> 1);
-        const int sw = BM == 128 ? (q4 << 2) : (((q4 >> 1) & 1) << 2);
-        a_addr[st][i] = sb + (8 * h + q4) * RB + ((c ^ sw) << 4) + ((p4 & 1) << 3);
-      }
+    for (int i = 0; i < TM; ++i) {
+      const int c = wm * 4 * TM + 4 * i + 2 * g1 + (p4 >> 1);
+      const int sw = BM == 128 ? (q4 << 2) : (((q4 >> 1) & 1) << 2);
+      a_addr0[i] = lds0 + (8 * h + q4) * RB + ((c ^ sw) << 4) + ((p4 & 1) << 3);
     }
-    if constexpr (!BT) {
+  }
+  if constexpr (!BT) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b_addr[st][ks] = sb + A_BYTES + (wn * 32 * TN + r32) * 128 + (((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4);
-    } else {
-      constexpr int RB = BN * 2;
+    for (int ks = 0; ks < 4; ++ks) b_addr0[ks] = lds0 + A_BYTES + (wn * 32 * TN + r32) * 128 + (((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4);
+  } else {
+    constexpr int RB = BN * 2;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int c = wn * 4 * TN + 4 * i + 2 * g1 + (p4 >> 1);
-        const int sw = BN == 128 ? (q4 << 2) : (((q4 >> 1) & 1) << 2);
-        b_addr[st][i] = sb + A_BYTES + (8 * h + q4) * RB + ((c ^ sw) << 4) + ((p4 & 1) << 3);
-      }
+    for (int i = 0; i < TN; ++i) {
+      const int c = wn * 4 * TN + 4 * i + 2 * g1 + (p4 >> 1);
+      const int sw = BN == 128 ? (q4 << 2) : (((q4 >> 1) & 1) << 2);
+      b_addr0[i] = lds0 + A_BYTES + (8 * h + q4) * RB + ((c ^ sw) << 4) + ((p4 & 1) << 3);
     }
   }
 
@@ -692,24 +688,29 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   auto compute = [&](auto st_) {
     constexpr int ST = decltype(st_)::value;
     bf16x8 af[4][TM], bfr[4][TN];
+    unsigned a_addr[1][NA], b_addr[1][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_addr[0][i] = a_addr0[i] + ST * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_addr[0][i] = b_addr0[i] + ST * STAGE_BYTES;
     auto read_ks = [&](auto ks_) {
       constexpr int KS = decltype(ks_)::value;
       gsfor<0, TM>([&](auto i_) {
         constexpr int I = decltype(i_)::value;
         if constexpr (!AT) {
-          af[KS][I] = gemm_lds128<I * 32 * 128>(a_addr[ST][KS]);
+          af[KS][I] = gemm_lds128<I * 32 * 128>(a_addr[0][KS]);
         } else {
           constexpr int RB = BM * 2;
-          af[KS][I] = join8(gemm_ldstr<KS * 16 * RB>(a_addr[ST][I]), gemm_ldstr<(KS * 16 + 4) * RB>(a_addr[ST][I]));
+          af[KS][I] = join8(gemm_ldstr<KS * 16 * RB>(a_addr[0][I]), gemm_ldstr<(KS * 16 + 4) * RB>(a_addr[0][I]));
         }
       });
       gsfor<0, TN>([&](auto i_) {
         constexpr int I = decltype(i_)::value;
         if constexpr (!BT) {
-          bfr[KS][I] = gemm_lds128<I * 32 * 128>(b_addr[ST][KS]);
+          bfr[KS][I] = gemm_lds128<I * 32 * 128>(b_addr[0][KS]);
         } else {
           constexpr int RB = BN * 2;
-          bfr[KS][I] = join8(gemm_ldstr<KS * 16 * RB>(b_addr[ST][I]), gemm_ldstr<(KS * 16 + 4) * RB>(b_addr[ST][I]));
+          bfr[KS][I] = join8(gemm_ldstr<KS * 16 * RB>(b_addr[0][I]), gemm_ldstr<(KS * 16 + 4) * RB>(b_addr[0][I]));
         }
       });
     };
@@ -794,10 +795,13 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
     // workgroups per CU, or a K split, the smaller footprint of two stages wins: 3072 x 1024 x 4096 dW 42 vs 49 us)
     static const int force_ns = getenv("BMHRL_GEMM_STAGES") ? atoi(getenv("BMHRL_GEMM_STAGES")) : 0;   // (tuning aid)
     const long blocks = (long)p.tiles_m * tiles_n * batch;
-    const bool deep = force_ns ? force_ns == 4 : (TM == 1 && splits == 1 && blocks <= 448);
+    // (Eight stages for the caption-side GEMMs -- 480 rows, 40 .. 128 tiles -- measured no better than four: 8.2 vs 7.3 us
+    // at 480 x 1024 x 1024; those launches sit on their fixed costs, not on the depth of the ring.)
+    int ns = TM == 1 && splits == 1 && blocks <= 448 ? 4 : 2;
+    if (force_ns) ns = TM == 1 ? (force_ns >= 4 ? 4 : 2) : 2;
 #define BMHRL_GLDS(AT_, BT_)                                                                                    \
     do {                                                                                                          \
-      if (TM == 1 && deep) hipLaunchKernelGGL((gemm_glds_kernel<TM, TN, AT_, BT_, TM == 1 ? 4 : 2>), grid, block, 0, s, p); \
+      if (TM == 1 && ns == 4) hipLaunchKernelGGL((gemm_glds_kernel<TM, TN, AT_, BT_, TM == 1 ? 4 : 2>), grid, block, 0, s, p); \
       else hipLaunchKernelGGL((gemm_glds_kernel<TM, TN, AT_, BT_, 2>), grid, block, 0, s, p);                   \
     } while (0)
     if (!a_trans && !b_trans) BMHRL_GLDS(false, false);

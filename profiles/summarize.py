@@ -19,10 +19,15 @@ if tr:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
         n = r["Kernel_Name"]
-        if "gemm_kernel" in n or "attn_fwd" in n:
-            short = "gemm" + n.split("gemm_kernel")[1].split("(")[0] if "gemm_kernel" in n else "attn_fwd"
+        if "gemm_kernel" in n or "gemm_glds_kernel" in n or "attn_" in n:
+            if "gemm_glds_kernel" in n:
+                short = "gemm_glds" + n.split("gemm_glds_kernel")[1].split("(")[0]
+            elif "gemm_kernel" in n:
+                short = "gemm" + n.split("gemm_kernel")[1].split("(")[0]
+            else:
+                short = "attn_" + n.split("attn_")[1].split("(")[0][:40]
             agg[(short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"], r["Grid_Size_Z"])].append(
                 (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("\n| kernel | blocks x | y | z | calls/step | avg us | ms/step |\n|---|---|---|---|---|---|---|")
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:40]:
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:50]:
         print(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {len(v) / steps:.1f} | {sum(v) / len(v):.1f} | {sum(v) / steps / 1e3:.3f} |")
