@@ -48,6 +48,8 @@ PROTOTYPES = {
                             f32, u64, ptr, ptr],
     "bmhrl_attention_shared128_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, i32, f32, ptr],
     "bmhrl_attention_config": [i32, i32],
+    "bmhrl_attention_shared128_bwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, i32, ptr, i32, i32,
+                                      i32, i32, f32, ptr],
     "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, ptr],
     "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
@@ -105,6 +107,8 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.bmhrl_layernorm_bwd_workspace.argtypes = [i64, i32]
     lib.bmhrl_layernorm_bwd_workspace.restype = C.c_int64
+    lib.bmhrl_attention_shared128_bwd_workspace.argtypes = [i32, i32, i32]
+    lib.bmhrl_attention_shared128_bwd_workspace.restype = C.c_int64
     lib.bmhrl_hip_arch.restype = C.c_char_p
     lib.bmhrl_hip_abi_version.restype = C.c_int
     _lib = lib

@@ -8,6 +8,7 @@ vocabulary logits and all reductions are fp32; GEMM and attention operands are b
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Optional
 
@@ -494,6 +495,11 @@ class MHAFn(torch.autograd.Function):
         return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None, None)
 
 
+# fused (flash-style) backward of the head-dimension-128 attention; BMHRL_FUSED_ATTN_BWD=0 keeps the materialised P / dS GEMMs
+# of r01 (A/B and parity tests of one form against the other)
+FUSED_ATTN_BWD = os.environ.get("BMHRL_FUSED_ATTN_BWD", "1") != "0"
+
+
 class MemAttnFn(torch.autograd.Function):
     """x + dropout( d2Q( attention( Q2d(LN(x)), K2d(mem), V2d(mem), mask ) ) ) for FEW queries against a LONG memory
     (the caption -> encoder-memory attentions of BMFusionLayer: 30 caption positions against 256 video / 800 audio
@@ -603,34 +609,49 @@ class MemAttnFn(torch.autograd.Function):
         # softmax backward: delta = sum_k P dP = sum_n dCx Cx ; dS = P (dP - delta) * scale with dP = dCx_h mem^T
         delta = torch.empty(B, H, L, device=dev)
         ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B, H, L, dmp)
-        dS = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
-        pstr = (L * H * Skp, Skp)
-        if flash:      # P (B, L, H, Sk) recomputed from the statistics of the fused forward
-            P = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
-            ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
-                     b_strides=(Sk * dmp, 0), C_bf16=P, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
-                     mask=m8, mask_sb1=msb, mask_sm=0, rowvec=stats[0], rowvec2=stats[1], rv_strides=(H * L, L))
-        else:
-            P = stats[0]
-        ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
-                 C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
-                 rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
-        # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h : two GEMMs with K = L*H (rows (l, h) of the (B, L, H, .) tensors)
-        def grad_mem(target, first_accumulates):
-            ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
-                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
-                     accumulate=first_accumulates)
-            ops.gemm(dS, Qp, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
-                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
-                     accumulate=True)
-        dmem = None
-        if need[1] and not self_att:
-            dmem = torch.empty(B, Sk, dm, device=dev)
-            grad_mem(dmem, False)
-        # scores = scale * Q'_h mem^T (scale is already inside dS)
         dQp = zeros(rows, H * dmp, dtype=_BF16, device=dev)
-        ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
-                 C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        dmem = None
+        dxn = None
+        if flash and FUSED_ATTN_BWD:
+            # fused: P and dS are recomputed per tile from the forward's statistics and stay on chip; one call yields
+            # dQ'_h = dS_h mem and d(mem) = sum_h P_h^T dCx_h + dS_h^T Q'_h (bmhrl_attention_shared128_bwd)
+            if self_att:
+                dxn = torch.empty(rows, dq, device=dev)       # d(LN(x)) starts as the key / value side's gradient ...
+                target = dxn
+            elif need[1]:
+                dmem = torch.empty(B, Sk, dm, device=dev)
+                target = dmem
+            else:
+                target = None
+            ops.attention_shared128_bwd(Qp, memb, dCx, stats[0], stats[1], delta, m8, msb, dQp, target, False, B, H, L, Sk,
+                                        scale, H * dmp, dmp, H * dmp, H * dmp, lddx=dm)
+        else:
+            dS = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
+            pstr = (L * H * Skp, Skp)
+            if flash:      # P (B, L, H, Sk) recomputed from the statistics of the fused forward
+                P = _padded_bf16(B * L * H, Sk, dev).view(B, L, H, Skp)
+                ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
+                         b_strides=(Sk * dmp, 0), C_bf16=P, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
+                         mask=m8, mask_sb1=msb, mask_sm=0, rowvec=stats[0], rowvec2=stats[1], rv_strides=(H * L, L))
+            else:
+                P = stats[0]
+            ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
+                     C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
+                     rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
+            # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h : two GEMMs with K = L*H (rows (l, h) of the (B, L, H, .) tensors)
+            def grad_mem(target, first_accumulates):
+                ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
+                         a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
+                         accumulate=first_accumulates)
+                ops.gemm(dS, Qp, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
+                         a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
+                         accumulate=True)
+            if need[1] and not self_att:
+                dmem = torch.empty(B, Sk, dm, device=dev)
+                grad_mem(dmem, False)
+            # scores = scale * Q'_h mem^T (scale is already inside dS)
+            ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
+                     C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
         # Q'_h = Q_h Wk_h
         dwk = None
         if need[6]:
@@ -643,9 +664,12 @@ class MemAttnFn(torch.autograd.Function):
                  b_strides=(0, dk * w_k.shape[1]), C_bf16=dQb, ldcb=D, cb_strides=(0, dk), colsum=dbq, colsum_sb2=dk)
         dbk = SCRATCH.f32(D, device=dev) if need[7] else None       # exactly zero: a shift of all keys' scores
         # Q projection and LayerNorm
-        dxn = torch.empty(rows, dq, device=dev)
-        dwq, _ = _linear_bwd(dQb, D, rows, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=False, need_dx=True, dx_f32=dxn)
-        if self_att:
+        fused_self = dxn is not None           # ... and the query path's gradient is added by the GEMM below
+        if dxn is None:
+            dxn = torch.empty(rows, dq, device=dev)
+        dwq, _ = _linear_bwd(dQb, D, rows, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=False, need_dx=True, dx_f32=dxn,
+                             dx_accumulate=fused_self)
+        if self_att and not fused_self:
             grad_mem(dxn, True)        # the keys / values are LN(x) too: their gradient joins the query path's
         dx = torch.empty(B, L, dq, device=dev)
         dlnw = SCRATCH.f32(dq, device=dev) if need[2] else None

@@ -85,6 +85,21 @@ def attention_shared128_fwd(Qp, X, ctx, row_max, row_sum, mask, mask_sb, B, H, S
                                                          B, H, Sq, Sk, scale, stream()), "bmhrl_attention_shared128_fwd")
 
 
+def attention_shared128_bwd(Qp, X, dCx, row_max, row_sum, delta, mask, mask_sb, dQp, dX, accumulate_dx, B, H, Sq, Sk, scale,
+                            ldq, ldx, lddo, lddq, lddx=128):
+    """fused backward of attention_shared128_fwd: dQp (bf16) and, when dX is given, dX (fp32 (B,Sk,128), += when
+    accumulate_dx) -- P / dS are recomputed per tile and never written to HBM"""
+    _need_cuda(Qp, X, dCx, dQp)
+    lib = _lib.load()
+    ws = None
+    if dX is not None:
+        ws = torch.empty(int(lib.bmhrl_attention_shared128_bwd_workspace(B, H, Sk)), device=Qp.device)
+    _lib.check(lib.bmhrl_attention_shared128_bwd(Qp.data_ptr(), ldq, X.data_ptr(), ldx, dCx.data_ptr(), lddo, row_max.data_ptr(),
+                                                 row_sum.data_ptr(), delta.data_ptr(), _p(mask), mask_sb, dQp.data_ptr(), lddq,
+                                                 _p(dX), lddx, int(bool(accumulate_dx)), _p(ws), B, H, Sq, Sk, scale, stream()),
+               "bmhrl_attention_shared128_bwd")
+
+
 def softmax_rows(S, lds, P, ldp, rows, cols):
     _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr(), ldp, rows, cols, stream()), "bmhrl_softmax_rows")
 

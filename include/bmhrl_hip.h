@@ -94,6 +94,19 @@ int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const void* X, in
                                   float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
                                   int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale, bmhrl_stream_t stream);
 
+/* Fused backward of bmhrl_attention_shared128_fwd (autograd of attention(), model/multihead_attention.py:7-31, in the
+ * absorbed-projection form): given dCx (B,Sq,H,128) bf16, the forward's statistics and delta[b,h,q] = sum_d dCx*Cx
+ * (bmhrl_attn_delta), writes dQp (B,Sq,H,128) bf16 and -- when dX != NULL -- dX (B,Sk,128) fp32 (leading dim lddx; += when
+ * accumulate_dx) = sum over heads of P_h^T dCx_h + dS_h^T Qp_h.  P and dS are recomputed per tile from the statistics and
+ * never written to memory; masked keys get no score gradient (masked_fill); deterministic (no atomics).  workspace:
+ * bmhrl_attention_shared128_bwd_workspace(B,H,Sk) fp32 elements (the per-head partials of dX), uninitialised is fine. */
+int64_t bmhrl_attention_shared128_bwd_workspace(int32_t B, int32_t H, int32_t Sk);
+int bmhrl_attention_shared128_bwd(const void* Qp, int64_t ldq, const void* X, int64_t ldx, const void* dCx, int64_t lddo,
+                                  const float* row_max, const float* row_sum, const float* delta, const uint8_t* mask,
+                                  int64_t mask_sb, void* dQp, int64_t lddq, float* dX, int64_t lddx, int32_t accumulate_dx,
+                                  float* workspace, int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale,
+                                  bmhrl_stream_t stream);
+
 /* Tuning aid: pin the (query blocks x key splits) shape of the attention workgroups -- head_dim 256 or 128; code = 10 * QW + KW
  * (41: 4 x 1, 22: 2 x 2), 0 = automatic (the default).  Process-wide, not thread-safe; results do not depend on it. */
 int bmhrl_attention_config(int32_t head_dim, int32_t code);

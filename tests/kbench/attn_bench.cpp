@@ -22,6 +22,14 @@
 #include "../../include/bmhrl_hip.h"
 
 extern "C" int bmhrl_attention_config(int32_t head_dim, int32_t code);
+extern "C" int64_t bmhrl_attention_shared128_bwd_workspace(int32_t B, int32_t H, int32_t Sk);
+extern "C" int bmhrl_attention_shared128_bwd(const void* Qp, int64_t ldq, const void* X, int64_t ldx, const void* dCx, int64_t lddo,
+                                             const float* row_max, const float* row_sum, const float* delta, const uint8_t* mask,
+                                             int64_t mask_sb, void* dQp, int64_t lddq, float* dX, int64_t lddx, int32_t accumulate_dx,
+                                             float* workspace, int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale,
+                                             bmhrl_stream_t stream);
+extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale, int32_t B,
+                                int32_t H, int32_t Sq, int32_t dk, bmhrl_stream_t stream);
 
 #define CK(x)                                                                          \
   do {                                                                                 \
@@ -297,6 +305,121 @@ int main(int argc, char** argv) {
     release(b);
     return 0;
   }
-  fprintf(stderr, "usage: attn_bench check | time [iters] | one form B H Sq Sk code maskmode [iters]\n");
+  if (mode == "bwdcheck" || mode == "bwdtime") {
+    // fused backward of the shared-128 form: forward (statistics, Cx) -> delta -> bmhrl_attention_shared128_bwd
+    const bool timing = mode == "bwdtime";
+    const Case small[] = {{128, 2, 2, 96, 100, 2, 0, 0}, {128, 3, 2, 33, 257, 3, 0, 0}, {128, 2, 4, 160, 200, 0, 0, 0},
+                          {128, 2, 2, 130, 64, 1, 1, 0}, {128, 8, 4, 256, 300, 2, 0, 0}, {128, 2, 4, 290, 260, 3, 0, 0}};
+    const Case big[] = {{128, 16, 4, 256, 800, 2, 0, 0}, {128, 16, 4, 800, 800, 2, 0, 0}, {128, 8, 4, 1024, 2048, 2, 0, 0}};
+    const Case* cases = timing ? big : small;
+    const int ncases = timing ? 3 : 6;
+    for (int ci = 0; ci < ncases; ++ci) {
+      const Case c = cases[ci];
+      Buffers b;
+      make(c, b, 4321u + c.Sq);
+      const size_t nq = (size_t)c.B * c.Sq * b.ldq;
+      std::vector<uint16_t> dcx(nq);
+      std::mt19937 rng(77);
+      std::normal_distribution<float> nd(0.f, 1.f);
+      for (auto& x : dcx) x = f2bf(nd(rng));
+      uint16_t *d_dcx, *d_dq;
+      float *d_delta, *d_dx, *d_ws;
+      CK(hipMalloc(&d_dcx, nq * 2));
+      CK(hipMalloc(&d_dq, nq * 2));
+      CK(hipMemcpy(d_dcx, dcx.data(), nq * 2, hipMemcpyHostToDevice));
+      CK(hipMalloc(&d_delta, (size_t)c.B * c.H * c.Sq * 4));
+      CK(hipMalloc(&d_dx, (size_t)c.B * c.Sk * 128 * 4));
+      CK(hipMalloc(&d_ws, (size_t)bmhrl_attention_shared128_bwd_workspace(c.B, c.H, c.Sk) * 4));
+      const float scale = 1.f / 16.f;
+      const uint8_t* m = c.maskmode == 0 ? nullptr : b.dmask;
+      auto run = [&](hipStream_t st) {
+        bmhrl_attn_delta(d_dcx, b.ldq, b.dout, b.ldo, d_delta, 1.f, c.B, c.H, c.Sq, 128, st);
+        return bmhrl_attention_shared128_bwd(b.dq, b.ldq, b.dk, b.ldk, d_dcx, b.ldq, b.dmax, b.dsum, d_delta, m, c.Sk, d_dq, b.ldq,
+                                             d_dx, 128, 0, d_ws, c.B, c.H, c.Sq, c.Sk, scale, st);
+      };
+      bmhrl_attention_config(128, 0);
+      if (launch(c, b, 0) != 0 || run(0) != 0) { printf("launch failed\n"); return 1; }
+      CK(hipDeviceSynchronize());
+      if (timing) {
+        hipStream_t st;
+        CK(hipStreamCreate(&st));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        std::vector<float> ms;
+        for (int rep = 0; rep < 5; ++rep) {
+          CK(hipEventRecord(e0, st));
+          for (int i = 0; i < 10; ++i) run(st);
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float t;
+          CK(hipEventElapsedTime(&t, e0, e1));
+          ms.push_back(t / 10);
+        }
+        std::sort(ms.begin(), ms.end());
+        const double gf = 14.0 * c.B * c.H * (double)c.Sq * c.Sk * 128 / 1e9;     // 7 products
+        printf("bwd shared128 B%d H%d Sq%d Sk%d: %.1f us (delta + dq + dx + reduce), %.0f TF/s executed\n", c.B, c.H, c.Sq, c.Sk,
+               ms[2] * 1e3, gf / (ms[2] * 1e3) * 1e3);
+        continue;
+      }
+      // fp64 reference of dQp and dX
+      std::vector<uint16_t> dq(nq);
+      std::vector<float> dx((size_t)c.B * c.Sk * 128);
+      CK(hipMemcpy(dq.data(), d_dq, nq * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(dx.data(), d_dx, dx.size() * 4, hipMemcpyDeviceToHost));
+      double wq = 0, rq = 0, wx = 0, rx = 0;
+      std::vector<double> S(c.Sk), P(c.Sk), dP(c.Sk), dXr((size_t)c.Sk * 128);
+      for (int bb = 0; bb < c.B; ++bb) {
+        std::fill(dXr.begin(), dXr.end(), 0.0);
+        for (int h = 0; h < c.H; ++h)
+          for (int q = 0; q < c.Sq; ++q) {
+            const uint16_t* qp = &b.q[((size_t)bb * c.Sq + q) * b.ldq + (size_t)h * 128];
+            const uint16_t* dp = &dcx[((size_t)bb * c.Sq + q) * b.ldq + (size_t)h * 128];
+            double mx = -1e300;
+            for (int k = 0; k < c.Sk; ++k) {
+              const uint16_t* xp = &b.k[((size_t)bb * c.Sk + k) * b.ldk];
+              double s0 = 0, d0 = 0;
+              for (int d = 0; d < 128; ++d) { s0 += (double)bf2f(qp[d]) * bf2f(xp[d]); d0 += (double)bf2f(dp[d]) * bf2f(xp[d]); }
+              const bool keep = c.maskmode == 0 || b.mask[(size_t)bb * c.Sk + k];
+              S[k] = keep ? s0 * scale : -1e9;
+              dP[k] = d0;
+              mx = std::max(mx, S[k]);
+            }
+            double l = 0;
+            for (int k = 0; k < c.Sk; ++k) { P[k] = std::exp(S[k] - mx); l += P[k]; }
+            double delta = 0;
+            for (int k = 0; k < c.Sk; ++k) { P[k] /= l; delta += P[k] * dP[k]; }
+            double dqr[128] = {0};
+            for (int k = 0; k < c.Sk; ++k) {
+              const bool keep = c.maskmode == 0 || b.mask[(size_t)bb * c.Sk + k];
+              const double ds = keep ? P[k] * (dP[k] - delta) * scale : 0.0;      // no gradient through masked_fill
+              const uint16_t* xp = &b.k[((size_t)bb * c.Sk + k) * b.ldk];
+              for (int d = 0; d < 128; ++d) {
+                dqr[d] += ds * bf2f(xp[d]);
+                dXr[(size_t)k * 128 + d] += P[k] * bf2f(dp[d]) + ds * bf2f(qp[d]);
+              }
+            }
+            for (int d = 0; d < 128; ++d) {
+              const double got = bf2f(dq[((size_t)bb * c.Sq + q) * b.ldq + (size_t)h * 128 + d]);
+              wq = std::max(wq, std::fabs(got - dqr[d]));
+              rq = std::max(rq, std::fabs(dqr[d]));
+            }
+          }
+        for (size_t i = 0; i < dXr.size(); ++i) {
+          wx = std::max(wx, std::fabs((double)dx[(size_t)bb * c.Sk * 128 + i] - dXr[i]));
+          rx = std::max(rx, std::fabs(dXr[i]));
+        }
+      }
+      const bool ok = wq <= 2e-2 * rq && wx <= 2e-2 * rx && std::isfinite(wq) && std::isfinite(wx);
+      printf("bwd shared128 B%d H%d Sq%d Sk%d mask%d spike%d: dQp err %.2e of max %.2e, dX err %.2e of max %.2e  %s\n", c.B, c.H,
+             c.Sq, c.Sk, c.maskmode, c.spike, wq, rq, wx, rx, ok ? "ok" : "FAIL");
+      all_ok &= ok;
+      (void)hipFree(d_dcx); (void)hipFree(d_dq); (void)hipFree(d_delta); (void)hipFree(d_dx); (void)hipFree(d_ws);
+      release(b);
+    }
+    if (!timing) printf(all_ok ? "ALL OK\n" : "FAILURES\n");
+    return all_ok ? 0 : 1;
+  }
+  fprintf(stderr, "usage: attn_bench check | time [iters] | one form B H Sq Sk code maskmode [iters] | bwdcheck | bwdtime\n");
   return 2;
 }

@@ -99,3 +99,57 @@ def test_shared128_masked_keys_do_not_matter_and_key_order_is_free():
     pout, plse = run(X[:, perm], mask[:, perm])
     assert float((pout - base).abs().max()) < 2e-2 * float(base.abs().max())
     assert float((plse - lse).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 4, 64, 64), (3, 2, 200, 130), (8, 4, 70, 200), (2, 4, 256, 800), (16, 4, 256, 800),
+                                       (4, 4, 800, 800), (2, 2, 96, 2100)])
+def test_shared128_fused_backward_matches_torch_autograd(B, H, Sq, Sk):
+    """bmhrl_attention_shared128_bwd (P / dS recomputed per tile, never in HBM) against torch autograd of the same attention
+    on the bf16-rounded operands: dQp and d(mem) incl. a padded tail, a fully masked sample (uniform attention: its values
+    get gradient, its scores none -- masked_fill has no gradient) and ragged query / key tiles."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 77 + Sq + 3 * Sk)
+    Qp = (0.5 * torch.randn(B, Sq, H, 128, generator=g)).to(dev).to(torch.bfloat16)
+    X = torch.randn(B, Sk, 128, generator=g).to(dev).to(torch.bfloat16)
+    dCx = torch.randn(B, Sq, H, 128, generator=g).to(dev).to(torch.bfloat16)
+    mask = torch.ones(B, Sk, dtype=torch.bool, device=dev)
+    mask[0, Sk - 37:] = False
+    mask[0, 3] = False
+    if B > 1:
+        mask[B - 1, :] = False
+    scale = 1.0 / 16
+    ctx = torch.empty(B, Sq, H, 128, dtype=torch.bfloat16, device=dev)
+    rmax = torch.empty(B, H, Sq, device=dev)
+    rsum = torch.empty(B, H, Sq, device=dev)
+    ops.attention_shared128_fwd(Qp, X, ctx, rmax, rsum, mask, Sk, B, H, Sq, Sk, scale, H * 128, 128, H * 128)
+    # reference: fp32 autograd
+    q32 = Qp.float().requires_grad_(True)
+    x32 = X.float().requires_grad_(True)
+    s = torch.einsum("bqhd,bkd->bhqk", q32, x32) * scale
+    s = s.masked_fill(~mask[:, None, None, :], -1e9)
+    ref = torch.einsum("bhqk,bkd->bqhd", torch.softmax(s, -1), x32)
+    ref.backward(dCx.float())
+    delta = torch.empty(B, H, Sq, device=dev)
+    # delta from the fp32 context (the kernel's own bf16 context differs by rounding only; the step uses the bf16 one)
+    ops.attn_delta(dCx, H * 128, ctx, H * 128, delta, B, H, Sq, 128)
+    dQp = torch.full((B, Sq, H, 128), 7.0, dtype=torch.bfloat16, device=dev)
+    dX = torch.full((B, Sk, 128), 3.0, device=dev)
+    ops.attention_shared128_bwd(Qp, X, dCx, rmax, rsum, delta, mask, Sk, dQp, dX, False, B, H, Sq, Sk, scale,
+                                H * 128, 128, H * 128, H * 128)
+    torch.cuda.synchronize()
+    eq = float((dQp.float() - q32.grad).abs().max() / q32.grad.abs().max())
+    ex = float((dX - x32.grad).abs().max() / x32.grad.abs().max())
+    assert eq < 2e-2 and ex < 2e-2, (eq, ex)
+    if B > 1:                                           # the fully masked sample: no score gradient at all
+        assert float(dQp[B - 1].float().abs().max()) == 0.0
+    # accumulate mode adds to what is there; dX = NULL skips the key-side kernel
+    dX2 = dX.clone()
+    ops.attention_shared128_bwd(Qp, X, dCx, rmax, rsum, delta, mask, Sk, dQp, dX2, True, B, H, Sq, Sk, scale,
+                                H * 128, 128, H * 128, H * 128)
+    assert float((dX2 - 2 * dX).abs().max()) <= 1e-5 * float(dX.abs().max())
+    ops.attention_shared128_bwd(Qp, X, dCx, rmax, rsum, delta, None if False else mask, Sk, dQp, None, False, B, H, Sq, Sk, scale,
+                                H * 128, 128, H * 128, H * 128)
+    torch.cuda.synchronize()
