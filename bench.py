@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--vocab", type=int, default=10172)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--mode", choices=("warmstart", "rl"), default="warmstart",
+                    help="warmstart = BASELINE configs[1] (the metric's config); rl = configs[2], the worker RL step of "
+                         "train_bimodal_bl with synthetic rewards (biased KL of sampled tokens + value-head update)")
     ap.add_argument("--eager", action="store_true", help="launch kernels step by step instead of replaying the HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="batch of the bounded CPU-oracle sample (default: the full B=16 step)")
@@ -239,10 +242,16 @@ def main():
     _lib.load()
 
     cfg = syn.default_cfg(dout_p=args.dropout, rl_att_layers=args.layers)
-    trainer = CaptionTrainer(cfg, args.vocab, dev, lr=1e-4)
-    trainer.agent.train()
-    trainer.agent.set_inference_mode(True)
+    rl = args.mode == "rl"
     b = syn.synthetic_batch(args.batch, args.tv, args.ta, args.len, args.vocab, seed=rank)
+    rewards = syn.synthetic_rewards(args.batch, b["captions"].shape[1] - 1, seed=2 + rank).to(dev) if rl else None
+    trainer = CaptionTrainer(cfg, args.vocab, dev, lr=1e-4, phase="worker" if rl else "warmstart",
+                             reward_fn=(lambda sampled, captions: rewards) if rl else None)
+    trainer.agent.train()
+    if rl:
+        trainer.value_net.train()
+    else:
+        trainer.agent.set_inference_mode(True)
     fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
     cap = b["captions"].to(dev)
 
@@ -282,7 +291,8 @@ def main():
             "B=16 batch on one GPU; whole-job aggregate over all GPUs)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BMHRL warmstart step (BASELINE configs[1]): B={args.batch}/GPU Tv={args.tv} Ta={args.ta} "
+            "config": {"workload": ("BMHRL worker RL step (BASELINE configs[2], synthetic rewards)" if rl else
+                                    "BMHRL warmstart step (BASELINE configs[1])") + f": B={args.batch}/GPU Tv={args.tv} Ta={args.ta} "
                                    f"L={args.len} V={args.vocab} N={args.layers} d_model=1024 H=4 dropout={args.dropout}",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": "hip-graph" if use_graph else "eager", "samples_per_s": args.steps * world * args.batch / elapsed},

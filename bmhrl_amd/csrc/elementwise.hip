@@ -819,4 +819,4 @@ extern "C" int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, 
 extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 2: bmhrl_gemm_desc.colsum, bmhrl_cast_colsum_bf16, bmhrl_cast_segments
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
-extern "C" int bmhrl_hip_abi_version(void) { return 5; }
+extern "C" int bmhrl_hip_abi_version(void) { return 6; }

@@ -231,7 +231,8 @@ __global__ void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const fl
 
 // Inverse-CDF categorical sample with one uniform per row (or arg-max), block per row.
 __global__ void sample_kernel(const float* __restrict__ logp, long ld, int64_t* __restrict__ out, float* __restrict__ p_out,
-                              int V, int greedy, uint64_t seed) {
+                              int V, int greedy, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += seed_dev[0];          // a device word advanced per step: fresh samples under graph replay
   __shared__ float part[256];
   __shared__ int best_i[256];
   const long row = blockIdx.x;
@@ -377,9 +378,10 @@ extern "C" int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int6
 }
 
 extern "C" int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
-                                   int32_t greedy, uint64_t seed, bmhrl_stream_t stream) {
+                                   int32_t greedy, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(logp && out && rows > 0 && V > 0);
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, out, p_out, V, greedy, seed);
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, out, p_out, V, greedy, seed,
+                     seed_dev);
   return hip_status(hipGetLastError());
 }
 

@@ -226,9 +226,9 @@ def log_softmax_bwd(dlogp, logp, ld, g_bf16, ldg, rows, V):
                "bmhrl_log_softmax_bwd")
 
 
-def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed):
+def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed, seed_dev=None):
     _lib.check(_lib.load().bmhrl_sample_tokens(logp.data_ptr(), ld, out.data_ptr(), _p(p_out), rows, V, int(greedy), seed,
-                                               stream()), "bmhrl_sample_tokens")
+                                               _p(seed_dev), stream()), "bmhrl_sample_tokens")
 
 
 def reinforce_fwd(pred, ld, action, value, critic_value, row_policy, row_value, rows, V, is_logp=True):

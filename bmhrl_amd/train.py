@@ -19,7 +19,7 @@ from . import ops, synthetic as syn
 from .functional import SCRATCH, SEEDS, SHADOWS
 from .loss.biased_kl import BiasedKL
 from .loss.label_smoothing import LabelSmoothing
-from .model.bm_hrl_agent import BMHrlAgent, BMWorkerValueFunction
+from .model.bm_hrl_agent import BMHrlAgent, BMManagerValueFunction, BMWorkerValueFunction
 from .model.masking import make_masks
 
 
@@ -176,7 +176,15 @@ class CaptionTrainer:
     """Owns agent + optimiser state for the captioning half of the reference's step on one GPU (one rank)."""
 
     def __init__(self, cfg, voc_size: int, device, lr: float = 1e-4, weight_decay: float = 0.0, seed: int = 0,
-                 critic_state: Optional[Dict[str, torch.Tensor]] = None, pad_idx: int = 1, smoothing: float = 0.7):
+                 critic_state: Optional[Dict[str, torch.Tensor]] = None, pad_idx: int = 1, smoothing: float = 0.7,
+                 phase: str = "warmstart", reward_fn=None, value_lr: float = 1e-4):
+        """phase: "warmstart" (label-smoothing KL, reference :1132-1189), "worker" or "manager" (the RL step of
+        train_bimodal_bl, reference :797-890: biased KL with sampled / arg-max tokens and their rewards + the value head's
+        masked-MSE update; the phase decides which modules are trainable, teach_worker / teach_manager :572-589).
+        reward_fn(sampled (B, L), captions) -> (B, L) rewards (BASELINE configs[2]: synthetic)."""
+        assert phase in ("warmstart", "worker", "manager")
+        self.phase = phase
+        self.reward_fn = reward_fn
         cfg.device = str(device)
         ds = SimpleNamespace(trg_voc_size=voc_size, train_vocab=SimpleNamespace(vectors=None))
         self.cfg = cfg
@@ -188,7 +196,21 @@ class CaptionTrainer:
         sd.update({"critic." + k: v for k, v in crit.items()})
         self.agent.load_state_dict(sd)
         self.agent.to(self.device)
-        self.agent.set_inference_mode(True)     # manager.exploration off (worker / warmstart phases)
+        if phase == "worker":
+            self.agent.teach_worker()           # bm_enc + worker fusion + worker trainable, manager side frozen, no exploration
+        elif phase == "manager":
+            self.agent.teach_manager()          # manager fusion + manager trainable (exploration noise on, as the reference)
+        else:
+            self.agent.set_inference_mode(True)     # manager.exploration off (warmstart)
+        self.value_net = None
+        if phase != "warmstart":
+            vcls = BMWorkerValueFunction if phase == "worker" else BMManagerValueFunction
+            self.value_net = vcls(cfg)
+            vshapes = {k: tuple(v.shape) for k, v in self.value_net.state_dict().items()}
+            self.value_net.load_state_dict(syn.fill_state_dict(vshapes, seed=seed + 7))
+            self.value_net.to(self.device)
+            self.vopt = FlatAdam(list(self.value_net.parameters()), lr=value_lr)
+        self.stabilize = bool(getattr(cfg, "rl_stabilize", False))
         self.pad_idx = pad_idx
         self.criterion = LabelSmoothing(smoothing, pad_idx)
         self.rl_criterion = BiasedKL(smoothing, pad_idx)
@@ -225,7 +247,9 @@ class CaptionTrainer:
         pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
         loss_mask = trg_y != self.pad_idx
         n_tokens = loss_mask.sum()
-        if rl is None:
+        if self.phase != "warmstart":
+            loss = self._rl_loss(pred, w_feat, m_feat, goals, seg, trg_y, loss_mask, n_tokens)
+        elif rl is None:
             loss = torch.sum(self.criterion(pred, trg_y)) / n_tokens
         else:
             sampled, score = rl
@@ -235,6 +259,22 @@ class CaptionTrainer:
         if self._world_scale() != 1.0:
             loss = loss * self.loss_weight       # global n_tokens normalisation (token_weight); a device scalar: graph-safe
         return loss, pred
+
+    def _rl_loss(self, pred, w_feat, m_feat, goals, seg, trg_y, loss_mask, n_tokens):
+        """worker / manager RL step of the reference (:846-877): value head on detached features, biased KL of the sampled
+        (worker) or arg-max (manager) tokens with their rewards, captioning loss / (n_tokens * 4/20) and the value head's
+        masked MSE against the rewards.  The two losses reach disjoint parameters (the features are detached), so one
+        backward pass serves both optimisers; sampling draws from a device seed word (fresh samples at every graph replay)."""
+        from .epoch_loops.captioning_bmrl_loops import biased_kl
+        worker = self.phase == "worker"
+        expected = (self.value_net((w_feat.detach(), goals.detach())) if worker else self.value_net(m_feat.detach())).squeeze(-1)
+        rows, scores, _, _ = biased_kl(worker, pred, None, expected.detach(), trg_y, None, loss_mask, seg, pred.device,
+                                       self.rl_criterion, self.stabilize, reward_fn=self.reward_fn, seed=12345, seed_dev=SEEDS.dev)
+        cap_loss = torch.sum(rows) / (n_tokens * (4.0 / 20.0))
+        vmask = loss_mask.float() if worker else seg.detach().float()
+        value_loss = (((expected - scores[0].float()) ** 2) * vmask).mean()
+        self.last_value_loss = value_loss.detach()
+        return cap_loss + value_loss
 
     def _sync_token_weight(self, captions):
         """before a step: this rank's share of the global token count -> self.loss_weight (in place: the captured step
@@ -247,15 +287,22 @@ class CaptionTrainer:
         trg_in, trg_y = captions[:, :-1].contiguous(), captions[:, 1:].contiguous()
         self._sync_token_weight(captions)
         self.opt.zero_grad()
+        if self.value_net is not None:
+            self.vopt.zero_grad()
         SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
         SHADOWS.refresh()
         loss, _ = self._forward_loss(fs, trg_in, trg_y, rl)
         loss.backward()
         self.opt.gather_grads()
+        if self.value_net is not None:
+            self.vopt.gather_grads()
         SCRATCH.end_step()
         scale = self.opt.all_reduce()
         self.opt.step(scale)
+        if self.value_net is not None:
+            self.vopt.all_reduce()
+            self.vopt.step(scale)
         return loss.detach()
 
     # ------------------------------------------------------------------ whole-step HIP graph
@@ -275,7 +322,10 @@ class CaptionTrainer:
                 if self._split():
                     for j in range(1, self.n_enc + 1):
                         self._graph_body_phase(j)
-                self._graph_body_b(self.opt.all_reduce())   # warm-up steps are real steps: replicas stay identical
+                scale = self.opt.all_reduce()               # warm-up steps are real steps: replicas stay identical
+                if self.value_net is not None:
+                    self.vopt.all_reduce()
+                self._graph_body_b(scale)
             SHADOWS.refresh()                 # builds the segment table of the one-launch shadow refresh (a host -> device
                                               # copy, not allowed while capturing); the captured body reuses it
         torch.cuda.current_stream().wait_stream(s)
@@ -307,6 +357,8 @@ class CaptionTrainer:
         return 1.0 / dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1.0
 
     def _split(self) -> bool:
+        if self.phase != "warmstart":
+            return False                          # (the RL phases take the one-phase backward + one all-reduce per bucket)
         if self.split_backward is None:
             import os
             if os.environ.get("BMHRL_SPLIT_BACKWARD") in ("0", "1"):      # tuning / rehearsal override
@@ -319,6 +371,8 @@ class CaptionTrainer:
         cap = st["captions"]
         trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
         self.opt.zero_grad()
+        if self.value_net is not None:
+            self.vopt.zero_grad()
         SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
         SHADOWS.invalidate()
@@ -335,6 +389,8 @@ class CaptionTrainer:
         else:
             loss.backward()
             self.opt.gather_grads()
+            if self.value_net is not None:
+                self.vopt.gather_grads()
             SCRATCH.end_step()
         self.static_loss.copy_(loss.detach())
 
@@ -358,6 +414,8 @@ class CaptionTrainer:
 
     def _graph_body_b(self, scale):
         self.opt.step(scale)
+        if self.value_net is not None:
+            self.vopt.step(scale)
 
     def replay(self, fs=None, captions=None):
         if fs is not None:
@@ -378,5 +436,7 @@ class CaptionTrainer:
                     w.wait()
         else:
             self.opt.all_reduce()
+            if self.value_net is not None:
+                self.vopt.all_reduce()
         self.graph_b.replay()
         return self.static_loss

@@ -223,10 +223,11 @@ int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, voi
 int bmhrl_smooth_kl_amp_grad(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg, const float* score,
                              const float* n_row, float smoothing, int32_t pad_idx, int32_t zero_pad_rows, float* out,
                              int64_t rows, int32_t V, bmhrl_stream_t stream);
-/* a ~ Categorical(exp(logp)) by inverse CDF with one uniform per row (counter RNG: seed, row);
+/* a ~ Categorical(exp(logp)) by inverse CDF with one uniform per row (counter RNG: seed (+ *seed_dev when given: a device
+ * word advanced per step, so that a captured step draws fresh samples at every replay), row);
  * greedy != 0 -> argmax.  epoch_loops/captioning_bmrl_loops.py:283-284 */
 int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
-                        int32_t greedy, uint64_t seed, bmhrl_stream_t stream);
+                        int32_t greedy, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
 /* Reinforce (loss/biased_kl.py:69-81): per-row terms of -adv*log(clamp(p(a), 1e-5, 1-1e-5)) and adv^2, adv = value -
  * critic_value; `pred` holds log-probs (is_logp = 1) or probabilities (0, the reference's input).  The backward
  * writes d(gscale * (mean(policy) + mean(value terms))) w.r.t. the (rows, V) probabilities, value and critic_value. */

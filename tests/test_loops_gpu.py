@@ -111,3 +111,31 @@ def test_trainer_graph_replay_matches_eager(setup):
     l_graph = [float(t2.replay()) for _ in range(3)]
     assert all(abs(a - g) < 2e-3 * abs(a) for a, g in zip(l_eager[1:], l_graph)), (l_eager, l_graph)
     assert l_eager[3] < l_eager[0]
+
+
+def test_trainer_rl_graph_replay_matches_eager(setup):
+    """The worker RL step (sampled tokens + synthetic rewards + value head) captured as one HIP graph == the eager step:
+    the sampler adds the device seed word, so replay k draws the same tokens as eager step k."""
+    from bmhrl_amd.train import CaptionTrainer
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    b = ds.batches[0]
+    cap = b["caption_data"].caption
+    rew = syn.synthetic_rewards(cap.shape[0], cap.shape[1] - 1, seed=5).to(dev)
+    fn = lambda sampled, captions: rew
+    mk = lambda: CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3, phase="worker",
+                                reward_fn=fn, value_lr=1e-3)
+    t1 = mk()
+    t1.agent.train(); t1.value_net.train()
+    m0 = t1.agent.manager.linear.weight.detach().clone()
+    v0 = t1.vopt.flat.clone()
+    l_eager = [float(t1.step(b["feature_stacks"], cap)) for _ in range(4)]
+    assert torch.equal(m0, t1.agent.manager.linear.weight)          # manager side frozen in the worker phase
+    assert not torch.equal(v0, t1.vopt.flat)                        # value head trained by the same backward
+    t2 = mk()
+    t2.agent.train(); t2.value_net.train()
+    t2.capture(b["feature_stacks"], cap, warmup=1)
+    assert t2.graph_b is None                                       # one graph: forward, sampling, backward, both Adams
+    l_graph = [float(t2.replay()) for _ in range(3)]
+    assert all(torch.isfinite(torch.tensor(l_eager)))
+    assert all(abs(a - g) < 2e-3 * abs(a) for a, g in zip(l_eager[1:], l_graph)), (l_eager, l_graph)
+    assert float((t1.vopt.flat - t2.vopt.flat).norm() / t1.vopt.flat.norm()) < 1e-3
