@@ -5,7 +5,8 @@
 
 Only the hot-path modules are aliased (model.bm_hrl_agent, model.blocks, model.multihead_attention, model.masking,
 model.encoder, model.decoder, model.utils,
-loss.label_smoothing, loss.biased_kl, epoch_loops.captioning_bmrl_loops, captioning_datasets.load_features); everything
+loss.label_smoothing, loss.biased_kl, epoch_loops.captioning_bmrl_loops, epoch_loops.validation_loops,
+captioning_datasets.load_features); everything
 else keeps resolving to the reference's own files."""
 import importlib
 import sys
@@ -22,6 +23,7 @@ ALIASES = {
     "loss.label_smoothing": "bmhrl_amd.loss.label_smoothing",
     "loss.biased_kl": "bmhrl_amd.loss.biased_kl",
     "epoch_loops.captioning_bmrl_loops": "bmhrl_amd.epoch_loops.captioning_bmrl_loops",
+    "epoch_loops.validation_loops": "bmhrl_amd.epoch_loops.validation_loops",
     "captioning_datasets.load_features": "bmhrl_amd.loader",
 }
 

@@ -10,16 +10,11 @@ from bmhrl_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def test_memoised_decode_equals_full_rerun():
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+def _agent(dev, V, **over):
     from types import SimpleNamespace
-    from bmhrl_amd.decode import greedy_decode
     from bmhrl_amd.model.bm_hrl_agent import BMHrlAgent
-    dev = torch.device("cuda:0")
-    cfg = syn.default_cfg(dout_p=0.0)
+    cfg = syn.default_cfg(dout_p=0.0, **over)
     cfg.device = str(dev)
-    V = 200
     agent = BMHrlAgent(cfg, SimpleNamespace(trg_voc_size=V, train_vocab=SimpleNamespace(vectors=None)))
     shapes = {k: tuple(v.shape) for k, v in agent.state_dict().items()}
     sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=0, clone_layers=True)
@@ -27,6 +22,16 @@ def test_memoised_decode_equals_full_rerun():
     agent.load_state_dict(sd)
     agent = agent.to(dev).eval()
     agent.set_inference_mode(True)
+    return agent
+
+
+def test_memoised_decode_equals_full_rerun():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd.decode import greedy_decode
+    dev = torch.device("cuda:0")
+    V = 200
+    agent = _agent(dev, V)
     b = syn.synthetic_batch(4, 64, 200, 12, V, seed=3)
     fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
     # end_idx = -1: never stop early, so both runs produce max_len tokens
@@ -37,7 +42,7 @@ def test_memoised_decode_equals_full_rerun():
     torch.cuda.synchronize()
     t_full = time.perf_counter() - t0
     t0 = time.perf_counter()
-    memo, first_memo = greedy_decode(agent, fs, 10, 2, -1, 1, "audio_video", return_first=True)
+    memo, first_memo = greedy_decode(agent, fs, 10, 2, -1, 1, "audio_video", return_first=True, incremental=False)
     torch.cuda.synchronize()
     t_memo = time.perf_counter() - t0
     assert torch.equal(full, memo)
@@ -61,3 +66,117 @@ def test_kv_cache_refuses_grad_mode():
         a = m.fused(x, kv, mask, kv_cache=cache)
         b = m.fused(x, kv, mask, kv_cache=cache)       # second call: projections come from the cache
         assert len(cache) == 1 and torch.equal(a, b) and torch.equal(a, m.fused(x, kv, mask))
+
+
+def _teacher_forced(agent, fs, toks):
+    from bmhrl_amd.model.masking import make_masks
+    trg = toks[:, :-1].contiguous()
+    with torch.no_grad():
+        return agent.inference(((fs["rgb"], fs["flow"]), fs["audio"]), trg, make_masks(fs, trg, "audio_video", 1))
+
+
+@pytest.mark.parametrize("B,Tv,Ta,V,graph", [(4, 64, 200, 200, True), (1, 40, 70, 120, True), (3, 100, 130, 300, False)])
+def test_incremental_decode_equals_prefix_rerun(B, Tv, Ta, V, graph):
+    """IncrementalDecoder (K|V rows appended per token, carried critic state, one HIP graph per token) against the full
+    forward over its own token prefix: every step's log-probs within 1e-3 (per element, floor 1), every token the arg-max
+    of the re-run unless the re-run's top-2 margin is below 1e-3, and -- while no such coin-flip occurs -- the same tokens
+    as the memoised prefix re-run decoder.  Segment labels (threshold 0.5: both classes occur) feed expand_goals."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd.decode import IncrementalDecoder, greedy_decode
+    dev = torch.device("cuda:0")
+    agent = _agent(dev, V, rl_critic_score_threshhold=0.5)
+    b = syn.synthetic_batch(B, Tv, Ta, 12, V, seed=4)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    L = 11
+    old = IncrementalDecoder.use_graph
+    IncrementalDecoder.use_graph = graph
+    try:
+        dec = IncrementalDecoder.for_batch(agent, fs, L, 2, -1, 1)
+        assert (dec.graph is not None) == graph
+        with torch.no_grad():
+            assert dec.begin(fs)
+            steps = []
+            for _ in range(L):
+                dec.step()
+                steps.append(dec.logp[:, 0].clone())
+            inc = dec.result()
+        assert inc.shape == (B, L + 1)
+        ref = _teacher_forced(agent, fs, inc)                  # (B, L, V)
+        got = torch.stack(steps, 1)
+        err = float(((got - ref).abs() / ref.abs().clamp_min(1.0)).max())
+        assert err < 1e-3, err
+        top2 = ref.topk(2, -1).values
+        sure = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert torch.equal(inc[:, 1:][sure], ref.argmax(-1)[sure])
+        assert float(sure.float().mean()) > 0.8
+        memo = greedy_decode(agent, fs, L, 2, -1, 1, "audio_video", incremental=False)
+        n_sure = int(sure.all(0).float().cumprod(0).sum())     # steps before the first coin-flip of any sample
+        assert torch.equal(memo[:, :n_sure + 1], inc[:, :n_sure + 1])
+        again = greedy_decode(agent, fs, L, 2, -1, 1, "audio_video")      # the cached decoder, second clip: state is reset
+        assert torch.equal(again, inc)
+        print(f"incremental decode B={B}: max log-prob error vs prefix re-run {err:.2e}, sure steps {n_sure}/{L}")
+    finally:
+        IncrementalDecoder.use_graph = old
+
+
+def test_incremental_decode_stops_like_the_reference_loop():
+    """early stop: the host looks at `done` every check_every tokens and the result is trimmed to the step at which the last
+    sample produced </s>; samples without memory keys (a fully masked modality) take the re-run path"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd.decode import IncrementalDecoder, greedy_decode
+    dev = torch.device("cuda:0")
+    V = 150
+    agent = _agent(dev, V)
+    b = syn.synthetic_batch(3, 64, 96, 12, V, seed=6)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    free = greedy_decode(agent, fs, 12, 2, -1, 1, "audio_video", incremental=False)
+    # a token every sample emits at some step (random weights repeat themselves): use the latest first occurrence
+    cands = [int(v) for v in free[0, 1:].unique() if all((free[r, 1:] == v).any() for r in range(3))]
+    if not cands:
+        pytest.skip("no common token in this synthetic decode")
+    last_first = lambda v: max(int((free[r, 1:] == v).float().argmax()) for r in range(3))
+    end = min(cands, key=last_first)
+    if last_first(end) >= 11:
+        pytest.skip("no token that ends every sample before max_len in this synthetic decode")
+    want = greedy_decode(agent, fs, 12, 2, end, 1, "audio_video", incremental=False)
+    assert want.shape[1] == last_first(end) + 2 < 13
+    old = IncrementalDecoder.check_every
+    try:
+        for every in (1, 4, 100):
+            IncrementalDecoder.check_every = every
+            got = greedy_decode(agent, fs, 12, 2, end, 1, "audio_video")
+            assert got.shape == want.shape and torch.equal(got, want), (every, got, want)
+    finally:
+        IncrementalDecoder.check_every = old
+    fs2 = {k: v.clone() for k, v in fs.items()}
+    fs2["audio"][1] = 0                                   # sample 1: no audio key at all -> uniform attention in the reference
+    dec = IncrementalDecoder.for_batch(agent, fs2, 12, 2, -1, 1)
+    with torch.no_grad():
+        assert not dec.begin(fs2)
+    a = greedy_decode(agent, fs2, 12, 2, -1, 1, "audio_video")
+    assert torch.equal(a, greedy_decode(agent, fs2, 12, 2, -1, 1, "audio_video", incremental=False))
+
+
+def test_incremental_decode_speed_config2():
+    """B=16, Tv=256, Ta=800, 30 tokens, V=10172 (the validation batch of BASELINE configs[1]): timing of the three schedules"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd.decode import greedy_decode
+    dev = torch.device("cuda:0")
+    V = 10172
+    agent = _agent(dev, V)
+    b = syn.synthetic_batch(16, 256, 800, 30, V, seed=0)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    times = {}
+    for name, kw in (("full", dict(memoise=False)), ("memoised", dict(incremental=False)), ("incremental", {})):
+        greedy_decode(agent, fs, 30, 2, -1, 1, "audio_video", **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = greedy_decode(agent, fs, 30, 2, -1, 1, "audio_video", **kw)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) * 1e3
+        assert toks.shape == (16, 31)
+    print("greedy decode of 30 tokens, B=16 (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in times.items()))
+    assert times["incremental"] < times["memoised"] < times["full"]

@@ -107,3 +107,47 @@ def test_agent_refuses_cpu_inputs():
     masks = make_masks({k: b[k] for k in ("rgb", "flow", "audio")}, trg, "audio_video", 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         agent((b["rgb"] + b["flow"], b["audio"]), trg, masks)
+
+
+def test_validation_1by1_host_side(tmp_path):
+    """validation_1by1_loop's host half (reference epoch_loops/validation_loops.py:53-118) with a stub decoder: ids -> words,
+    cut at </s>, capitalise, results grouped per video, the JSON file name and the duplicate-file rule"""
+    import json
+    from types import SimpleNamespace
+    import torch
+    from bmhrl_amd.epoch_loops.validation_loops import tokens_to_sentences, validation_1by1_loop
+    itos = ["<unk>", "<blank>", "<s>", "</s>", "a", "man", "runs", "fast"]
+    assert tokens_to_sentences([[2, 4, 5, 6, 3, 7, 7], [2, 5, 6, 7, 7, 7, 7], [2, 3, 4, 4, 4, 4, 4]], itos) == \
+        ["A man runs", "Man runs fast fast fast fast", ""]
+    ds = SimpleNamespace(start_idx=2, end_idx=3, pad_idx=1, phase="val_1", train_vocab=SimpleNamespace(itos=itos),
+                         update_iterator=lambda: None)
+    batches = [dict(feature_stacks={"k": i}, video_ids=["v1", "v2"] if i == 0 else ["v1", "v3"],
+                    starts=torch.tensor([[0.0], [1.5]]), ends=torch.tensor([[2.0], [3.5]])) for i in range(2)]
+    loader = SimpleNamespace(dataset=ds, __iter__=None)
+
+    class Loader(list):
+        dataset = ds
+    calls = []
+
+    def decoder(model, fs, max_len, start, end, pad, modality):
+        calls.append((model, fs["k"], max_len, start, end, pad, modality))
+        return torch.tensor([[2, 4, 5, 3, 1], [2, 6, 7, 7, 7]])
+
+    class Model:
+        module = "the-agent"
+        def eval(self):
+            calls.append("eval")
+    cfg = SimpleNamespace(max_len=4, modality="audio_video", log_path=None, reference_paths=["r1", "r2", "r3", "r4"],
+                          max_prop_per_vid=100, tIoUs=[0.3, 0.5, 0.7, 0.9])
+    assert validation_1by1_loop(cfg, Model(), Loader(batches), decoder, 3, None) is None       # log_path None -> None
+    assert calls[0] == "eval" and calls[1] == ("the-agent", 0, 4, 2, 3, 1, "audio_video")
+    cfg.log_path = str(tmp_path / "logs")
+    out = validation_1by1_loop(cfg, Model(), Loader(batches), decoder, 3, None)
+    path = tmp_path / "logs" / "captioning_results_val_1_e3.json"
+    saved = json.load(open(path))
+    assert saved["version"] == "VERSION 1.0" and saved["external_data"] == {"used": True, "details": ""}
+    assert saved["results"]["v1"] == [{"sentence": "A man", "timestamp": [0.0, 2.0]}] * 2
+    assert saved["results"]["v3"] == [{"sentence": "Runs fast fast fast", "timestamp": [1.5, 3.5]}]
+    assert out["submission_path"] == str(path)           # no evaluator in this image: the predictions come back
+    out2 = validation_1by1_loop(cfg, Model(), Loader(batches), decoder, 3, None)
+    assert out2["submission_path"] != str(path) and out2["submission_path"].startswith(str(path)[:-5] + "_")

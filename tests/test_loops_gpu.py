@@ -139,3 +139,27 @@ def test_trainer_rl_graph_replay_matches_eager(setup):
     assert all(torch.isfinite(torch.tensor(l_eager)))
     assert all(abs(a - g) < 2e-3 * abs(a) for a, g in zip(l_eager[1:], l_graph)), (l_eager, l_graph)
     assert float((t1.vopt.flat - t2.vopt.flat).norm() / t1.vopt.flat.norm()) < 1e-3
+
+
+def test_validation_1by1_loop_decodes_the_loader(setup, tmp_path):
+    """the one-by-one validation pass (reference epoch_loops/validation_loops.py:13-137) through the incremental decoder:
+    one sentence per clip in the ActivityNet-captions result dictionary, same tokens as the prefix re-run decoder"""
+    import json
+    from epoch_loops.validation_loops import validation_1by1_loop
+    from epoch_loops.captioning_bmrl_loops import bmhrl_greedy_decoder
+    from bmhrl_amd.decode import greedy_decode
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    cfg.max_len, cfg.modality, cfg.log_path = 6, "audio_video", str(tmp_path)
+    cfg.reference_paths, cfg.max_prop_per_vid = ["a", "b", "c", "d"], 100
+    ds.phase = "val_1"
+    ds.train_vocab.itos[3] = "</s>"
+    wrapped = SimpleNamespace(module=agent, eval=agent.eval)
+    agent.set_inference_mode(True)
+    out = validation_1by1_loop(cfg, wrapped, loader, bmhrl_greedy_decoder, 0, None)
+    saved = json.load(open(out["submission_path"]))["results"]
+    assert sorted(saved) == [f"v{j}" for j in range(4)] and all(len(v) == 3 for v in saved.values())
+    toks = greedy_decode(agent, ds.batches[0]["feature_stacks"], 6, 2, 3, 1, "audio_video", incremental=False).cpu()
+    words = [ds.train_vocab.itos[int(i)] for i in toks[0]][1:]
+    words = words[:words.index("</s>")] if "</s>" in words else words
+    assert saved["v0"][0]["sentence"] == " ".join(words).capitalize()
+    ds.phase = "train"
