@@ -560,6 +560,80 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// Adam over the flat bucket, parameter by parameter, writing each updated weight's bf16 shadow (or fp32 copy: concatenated
+// biases) in the same pass: the per-step shadow refresh (cast_segments over every weight: 221 MB read again) disappears.
+// seg = 6 int64 per parameter: offset in the flat bucket (elements), shadow address (0: none), rows, cols, shadow leading
+// dimension (elements; <= 0: the shadow is fp32, tightly packed), first block.  Block = 4096 consecutive elements.
+__global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg, float* __restrict__ p, const float* __restrict__ g,
+                                     float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps,
+                                     float wd, float bc1, float bc2_sqrt, float gscale, const int32_t* __restrict__ step_dev) {
+  if (step_dev) {
+    const float st = (float)step_dev[0];
+    bc1 = 1.f - powf(b1, st);
+    bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid * SEG_WORDS + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* e = seg + lo * SEG_WORDS;
+  const long off = e[0], rows = e[2], cols = e[3], ldd = e[4];
+  const long total = rows * cols;
+  const long base = ((long)blockIdx.x - e[5]) * SEG_ELEMS_PER_BLOCK;
+  const long end = base + SEG_ELEMS_PER_BLOCK < total ? base + SEG_ELEMS_PER_BLOCK : total;
+  const float step_size = lr / bc1;
+  auto upd = [&](const long i) -> float {
+    float gi = g[off + i] * gscale;
+    const float pi = p[off + i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[off + i] + (1.f - b1) * gi;
+    const float vi = b2 * v[off + i] + (1.f - b2) * gi * gi;
+    m[off + i] = mi;
+    v[off + i] = vi;
+    const float pn = pi - step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[off + i] = pn;
+    return pn;
+  };
+  if (e[1] == 0) {
+    for (long i = base + threadIdx.x; i < end; i += blockDim.x) upd(i);
+    return;
+  }
+  if (ldd <= 0) {
+    float* __restrict__ dst = reinterpret_cast<float*>(e[1]);
+    for (long i = base + threadIdx.x; i < end; i += blockDim.x) dst[i] = upd(i);
+    return;
+  }
+  bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(e[1]);
+  if ((cols & 3) == 0 && (ldd & 3) == 0 && (off & 3) == 0 && (e[1] & 7) == 0) {     // 16-byte accesses of the four arrays
+    for (long i = base + 4 * threadIdx.x; i < end; i += 4 * blockDim.x) {
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + off + i);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(p + off + i);
+      f32x4 mv = *reinterpret_cast<const f32x4*>(m + off + i), vv = *reinterpret_cast<const f32x4*>(v + off + i), pn;
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gi = gv[j] * gscale;
+        if (wd != 0.f) gi += wd * pv[j];
+        mv[j] = b1 * mv[j] + (1.f - b1) * gi;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gi * gi;
+        pn[j] = pv[j] - step_size * mv[j] / (sqrtf(vv[j]) / bc2_sqrt + eps);
+        o[j] = (bf16_t)pn[j];
+      }
+      *reinterpret_cast<f32x4*>(m + off + i) = mv;
+      *reinterpret_cast<f32x4*>(v + off + i) = vv;
+      *reinterpret_cast<f32x4*>(p + off + i) = pn;
+      const long r = i / cols, c = i - r * cols;
+      *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = o;
+    }
+  } else {
+    for (long i = base + threadIdx.x; i < end; i += blockDim.x) {
+      const long r = i / cols, c = i - r * cols;
+      dst[r * ldd + c] = (bf16_t)upd(i);
+    }
+  }
+}
+
 inline unsigned grid_for(long total, int block = 256, int cap = 2048) {
   long g = (total + block - 1) / block;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -816,7 +890,20 @@ extern "C" int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, 
   return hip_status(hipGetLastError());
 }
 
+extern "C" int bmhrl_adam_segments(const int64_t* segments, int32_t n_segments, int32_t n_blocks, float* param, const float* grad,
+                                   float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int32_t step, const int32_t* step_dev, float grad_scale,
+                                   bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(segments && n_segments > 0 && n_blocks > 0 && param && grad && exp_avg && exp_avg_sq && (step >= 1 || step_dev));
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_segments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, S_(stream), segments, n_segments, param, grad,
+                     exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, step_dev);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 2: bmhrl_gemm_desc.colsum, bmhrl_cast_colsum_bf16, bmhrl_cast_segments
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
-extern "C" int bmhrl_hip_abi_version(void) { return 6; }
+// 7: bmhrl_adam_segments
+extern "C" int bmhrl_hip_abi_version(void) { return 7; }

@@ -72,18 +72,33 @@ class ShadowCache:
         return buf
 
 
-    # ---- whole-cache refresh in one launch (training steps: every weight changes every step)
+    # ---- refresh of every stale entry in one launch
+    def _is_current(self, e):
+        params = tuple(r() for r in e[2])
+        return all(p is not None for p in params) and e[0] == self._version(params)
+
+    def mark_stale(self, kind, key):
+        """the parameters of this entry were written behind autograd's back (optimizer kernel) without their shadow"""
+        store = self.w if kind else self.b
+        e = store.get(key)
+        if e is not None:
+            store[key] = (None, e[1], e[2])
+
     def refresh(self):
-        """Re-cast every cached weight shadow and concatenated bias with ONE kernel launch and mark the entries
-        current, so the lookups of the following forward / backward are hits.  The segment table is rebuilt only when
-        the set of cached entries changed (the first step of a model populates the cache through the per-weight path)."""
+        """Re-cast every STALE cached weight shadow and concatenated bias with ONE kernel launch and mark the entries
+        current, so the lookups of the following forward / backward are hits.  (The optimizer keeps the shadows of the
+        parameters it owns current itself -- bmhrl_adam_segments writes them in the Adam pass -- so in a training step this
+        usually finds nothing to do.)  Segment tables are cached per set of stale entries."""
         live = [(k, e, 1) for k, e in self.w.items() if all(r() is not None for r in e[2])] + \
                [(k, e, 0) for k, e in self.b.items() if all(r() is not None for r in e[2])]
-        live = [(k, e, kind) for k, e, kind in live if e[1].is_cuda]
+        live = [(k, e, kind) for k, e, kind in live if e[1].is_cuda and not self._is_current(e)]
         if not live:
             return
         sig = tuple((k, kind, e[1].data_ptr()) + tuple(r().data_ptr() for r in e[2]) for k, e, kind in live)
-        if getattr(self, "_plan_sig", None) != sig:
+        plans = self.__dict__.setdefault("_plans", {})
+        if sig not in plans:
+            if len(plans) > 16:
+                plans.clear()
             rows_, blk = [], 0
             for k, e, kind in live:
                 buf, off = e[1], 0
@@ -100,9 +115,8 @@ class ShadowCache:
                         off += n
                         blk += (n + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
             dev = live[0][1][1].device
-            self._plan = (torch.tensor(rows_, dtype=torch.int64).to(dev), len(rows_), blk)
-            self._plan_sig = sig
-        table, n_seg, n_blk = self._plan
+            plans[sig] = (torch.tensor(rows_, dtype=torch.int64).to(dev), len(rows_), blk)
+        table, n_seg, n_blk = plans[sig]
         ops.cast_segments(table, n_seg, n_blk)
         for k, e, kind in live:
             params = tuple(r() for r in e[2])

@@ -280,3 +280,13 @@ def rnn_wavefront(layers, B, L, H, chunk=1):
 def critic_head(x, w, b, threshold, score, labels, rows, H):
     _lib.check(_lib.load().bmhrl_critic_head(x.data_ptr(), w.data_ptr(), b.data_ptr(), threshold, _p(score), _p(labels), rows, H,
                                              stream()), "bmhrl_critic_head")
+
+
+def adam_segments(table, n_segments, n_blocks, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
+                  grad_scale=1.0, step_dev=None):
+    """Adam over the flat bucket through a per-parameter table that also names each weight's bf16 shadow (see
+    bmhrl_adam_segments in include/bmhrl_hip.h)"""
+    _need_cuda(table, param)
+    _lib.check(_lib.load().bmhrl_adam_segments(table.data_ptr(), n_segments, n_blocks, param.data_ptr(), grad.data_ptr(),
+                                               exp_avg.data_ptr(), exp_avg_sq.data_ptr(), lr, beta1, beta2, eps, weight_decay,
+                                               step, _p(step_dev), grad_scale, stream()), "bmhrl_adam_segments")

@@ -10,6 +10,7 @@
 from __future__ import annotations
 
 from types import SimpleNamespace
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -52,6 +53,53 @@ class FlatAdam:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+
+    fused_shadows = os.environ.get("BMHRL_FUSED_SHADOWS", "1") == "1"   # False: plain Adam kernel + a whole-cache shadow refresh at the start of the next step
+
+    def _segment_plan(self):
+        """(table, n_segments, n_blocks, uncovered shadow entries) for ops.adam_segments, or None while it cannot be built
+        (during a graph capture before a warm-up step made it).  One row per parameter in bucket order; a parameter that
+        belongs to a live shadow group all of whose members this optimizer owns gets the address of its rows in the group's
+        bf16 buffer (or of its slice of the concatenated bias)."""
+        index = self.__dict__.setdefault("_index", {id(p): i for i, p in enumerate(self.params)})
+        dev = self.flat.device
+        groups = []
+        for kind, store in ((1, SHADOWS.w), (0, SHADOWS.b)):
+            for key, e in store.items():
+                params = [r() for r in e[2]]
+                if any(p is None for p in params) or e[1].device != dev:
+                    continue
+                mine = [id(p) in index and self.params[index[id(p)]] is p for p in params]
+                if any(mine):
+                    groups.append((kind, key, e[1], params, all(mine)))
+        sig = tuple((kind, key, buf.data_ptr()) for kind, key, buf, _, _ in groups)
+        cached = self.__dict__.get("_seg_plan")
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        dst, uncovered = {}, []
+        for kind, key, buf, params, all_mine in groups:
+            if not all_mine or any(id(p) in dst for p in params):
+                uncovered.append((kind, key))
+                continue
+            off = 0
+            for p in params:
+                if kind:
+                    n, kk, ld = p.shape[0], p.shape[1], buf.shape[1]
+                    dst[id(p)] = (buf.data_ptr() + 2 * off * ld, n, kk, ld)
+                    off += n
+                else:
+                    dst[id(p)] = (buf.data_ptr() + 4 * off, 1, p.numel(), 0)
+                    off += p.numel()
+        rows, blk = [], 0
+        for p, o, sz in zip(self.params, self.offsets, self.sizes):
+            d = dst.get(id(p), (0, 1, sz, 0))
+            rows.append([o, d[0], d[1], d[2], d[3], blk])
+            blk += (sz + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
+        plan = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), blk, uncovered)
+        self._seg_plan = (sig, plan)
+        return plan
 
     def set_buckets(self, counts: List[int]):
         """consecutive runs of `counts[i]` parameters form bucket i, in the order backward completes their gradients"""
@@ -128,8 +176,19 @@ class FlatAdam:
         b1, b2 = self.betas
         if self.flat.is_cuda:
             self.step_dev.add_(1)
-            ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, self.lr, b1, b2, self.eps,
-                          self.weight_decay, self.step_count, grad_scale, step_dev=self.step_dev)
+            plan = self._segment_plan() if self.fused_shadows else None
+            if plan is None:
+                ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, self.lr, b1, b2, self.eps,
+                              self.weight_decay, self.step_count, grad_scale, step_dev=self.step_dev)
+            else:
+                # the update also writes the bf16 shadows (and concatenated-bias copies) of the weights it owns: they stay
+                # current without the per-step refresh pass; shadows it could not place (a parameter in two groups) go stale
+                table, n_seg, n_blk, uncovered = plan
+                ops.adam_segments(table, n_seg, n_blk, self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, b1, b2,
+                                  self.eps, self.weight_decay, self.step_count, grad_scale, step_dev=self.step_dev)
+                for kind, key in uncovered:
+                    SHADOWS.mark_stale(kind, key)
+                return
         else:  # host-side reference used by the gloo tests of the data-parallel plumbing (no model arithmetic)
             g = self.grad * grad_scale
             if self.weight_decay:
@@ -375,8 +434,9 @@ class CaptionTrainer:
             self.vopt.zero_grad()
         SCRATCH.begin_step(self.device)
         SEEDS.dev.add_(1)
-        SHADOWS.invalidate()
-        SHADOWS.refresh()
+        if not self.opt.fused_shadows:
+            SHADOWS.invalidate()
+        SHADOWS.refresh()                     # (fused_shadows: the Adam pass keeps the shadows current -- nothing to do here)
         loss, _ = self._forward_loss(st, trg_in, trg_y)
         if self._split():
             # phase 0 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)

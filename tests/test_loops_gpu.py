@@ -163,3 +163,42 @@ def test_validation_1by1_loop_decodes_the_loader(setup, tmp_path):
     words = words[:words.index("</s>")] if "</s>" in words else words
     assert saved["v0"][0]["sentence"] == " ".join(words).capitalize()
     ds.phase = "train"
+
+
+def test_adam_pass_keeps_weight_shadows_current(setup):
+    """bmhrl_adam_segments writes the bf16 shadow of every weight it updates: after a step each cached shadow equals the
+    bf16 cast of its parameter without a refresh pass, and the losses equal those of the plain Adam kernel + refresh"""
+    from bmhrl_amd.functional import SHADOWS
+    from bmhrl_amd.train import CaptionTrainer, FlatAdam
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    b = ds.batches[1]
+    cap = b["caption_data"].caption
+    losses = {}
+    for fused in (True, False):
+        FlatAdam.fused_shadows = fused
+        try:
+            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+            t.agent.train()
+            losses[fused] = [float(t.step(b["feature_stacks"], cap)) for _ in range(3)]
+            if fused:
+                mine = {id(p) for p in t.opt.params}
+                n_checked = 0
+                for store, is_w in ((SHADOWS.w, True), (SHADOWS.b, False)):
+                    for key, (ver, buf, refs) in store.items():
+                        params = [r() for r in refs]
+                        if any(p is None or id(p) not in mine for p in params):
+                            continue
+                        assert ver == SHADOWS._version(tuple(params))          # marked current ...
+                        off = 0
+                        for p in params:                                       # ... and really is
+                            if is_w:
+                                assert torch.equal(buf[off:off + p.shape[0], :p.shape[1]], p.detach().to(torch.bfloat16))
+                                off += p.shape[0]
+                            else:
+                                assert torch.equal(buf[off:off + p.numel()], p.detach().reshape(-1))
+                                off += p.numel()
+                            n_checked += 1
+                assert n_checked > 50
+        finally:
+            FlatAdam.fused_shadows = True
+    assert all(abs(a - c) <= 2e-3 * abs(c) for a, c in zip(losses[True], losses[False])), losses
