@@ -11,7 +11,7 @@ line = [l for l in open(log) if l.startswith('{"metric"')][-1]
 b = json.loads(line)
 print(f"bench line of this run: {b['ms_per_step']:.3f} ms/step under the tracer (graph launches become host-bound: 761 nodes are "
       f"submitted one by one), roofline.launch_us {b['roofline']['launch_us']:.2f}\n")
-last_adam = max(i for i, e in enumerate(ev) if "adam_kernel" in e[2])
+last_adam = max(i for i, e in enumerate(ev) if "adam_" in e[2])
 tail = collections.defaultdict(list)
 for s, e, n, blk in ev[last_adam + 1:]:
     if "attn_fwd_kernel" in n or "gemm_kernel" in n:

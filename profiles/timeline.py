@@ -6,7 +6,7 @@ d, steps = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 # a step ends with the Adam kernel
-ends = [i for i, e in enumerate(ev) if "adam_kernel" in e[2]]
+ends = [i for i, e in enumerate(ev) if "adam_" in e[2]]
 first = ends[-steps - 1] + 1
 seg = ev[first:ends[-1] + 1]
 t0, t1 = seg[0][0], max(e[1] for e in seg)

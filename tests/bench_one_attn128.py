@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bmhrl_amd import ops
 dev = torch.device("cuda:0")
 B, H = 16, 4
-for Sq, Sk in ((256, 800), (800, 800)):
+SHAPES = {"va": ((256, 800),), "aa": ((800, 800),)}.get(os.environ.get("ATTN_SHAPE", ""), ((256, 800), (800, 800)))
+for Sq, Sk in SHAPES:
     Qp = torch.randn(B, Sq, H, 128, device=dev).to(torch.bfloat16)
     X = torch.randn(B, Sk, 128, device=dev).to(torch.bfloat16)
     mask = torch.ones(B, Sk, dtype=torch.bool, device=dev)
