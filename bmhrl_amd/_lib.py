@@ -47,6 +47,9 @@ PROTOTYPES = {
     "bmhrl_attention_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, f32,
                             f32, u64, ptr, ptr],
     "bmhrl_attention_shared128_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, i32, f32, ptr],
+    "bmhrl_attention_fwd_f16": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, f32,
+                                f32, u64, ptr, ptr],
+    "bmhrl_attention_shared128_fwd_f16": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, i32, f32, ptr],
     "bmhrl_attention_config": [i32, i32],
     "bmhrl_attention_shared128_bwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, i32, ptr, i32, i32,
                                       i32, i32, f32, ptr],

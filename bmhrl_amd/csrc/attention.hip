@@ -75,33 +75,8 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
                                    int64_t mask_sb, int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk,
                                    int32_t dk, float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                    bmhrl_stream_t stream) {
-  constexpr int DK = 256;
-  BMHRL_CHECK_ARG(Q && K && V && O && row_max && row_sum);
-  BMHRL_CHECK_ARG(dk == DK);  // d_model 1024 / H 4 of the reference; other head sizes use the materialised path
-  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
-  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
-  BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldk >= (int64_t)H * DK && ldv >= (int64_t)H * DK && ldo >= (int64_t)H * DK);
-  BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0);
-  BMHRL_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
-  BMHRL_CHECK_ARG((int64_t)Sk * ldk * 2 < (1ll << 31) && (int64_t)Sk * ldv * 2 < (1ll << 31));   // 32-bit lane offsets
-  AttnArgs a;
-  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
-  a.O = (bf16_t*)O; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
-  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
-  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev;
-  a.k_hs = DK; a.v_hs = DK;
-  a.dbg = g_attn_dbg;
-  // 4 x 1 (128 query rows per workgroup, every wave sees every key: no merge, K fragments requested across the barrier)
-  // as soon as that gives most CUs a workgroup; else 2 x 2 (64 rows, two key halves).  Measured on MI355X at B16 H4
-  // (tests/kbench/attn_bench time): Sq800 Sk256 35.0 vs 47.5 us, Sq256 Sk256 17.4 vs 14.4 us, Sq256 Sk800 36 vs 28 us.
-  int code = g_cfg256;
-  if (code == 0) code = ((int64_t)B * H * ((Sq + 127) / 128) >= 200) ? 41 : 22;
-  hipError_t e;
-  if (code == 41) e = launch_attn<DK, 4, 1, 3, false, true>(a, (hipStream_t)stream);
-  else if (code == 22) e = launch_attn<DK, 2, 2, 2, false, false>(a, (hipStream_t)stream);
-  else return -22;
-  attn_trace_dump("attn256", Sq, Sk, (hipStream_t)stream);
-  return hip_status(e);
+  return attention256_entry(Q, ldq, K, ldk, V, ldv, O, ldo, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale,
+                            dropout_p, seed, seed_dev, g_cfg256, (hipStream_t)stream);
 }
 
 extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale,

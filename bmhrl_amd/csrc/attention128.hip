@@ -16,37 +16,9 @@ extern "C" int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const 
                                              float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
                                              int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale,
                                              bmhrl_stream_t stream) {
-  constexpr int DK = 128;
-  BMHRL_CHECK_ARG(Qp && X && ctx && row_max && row_sum);
-  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
-  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0);
-  BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldx >= DK && ldo >= (int64_t)H * DK);
-  BMHRL_CHECK_ARG((((uintptr_t)Qp | (uintptr_t)X | (uintptr_t)ctx) & 15) == 0);
-  BMHRL_CHECK_ARG((int64_t)Sk * ldx * 2 < (1ll << 31));
-  AttnArgs a;
-  a.Q = (const bf16_t*)Qp; a.ldq = ldq; a.K = (const bf16_t*)X; a.ldk = ldx; a.V = (const bf16_t*)X; a.ldv = ldx;
-  a.O = (bf16_t*)ctx; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
-  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = 0;
-  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = 0.f; a.seed = 0; a.seed_dev = nullptr;
-  a.k_hs = 0; a.v_hs = 0;                       // one 128-wide key / value row for every head
-  a.dbg = g_attn_dbg;
-  // 4 x 1 (128 query rows per workgroup, two workgroups per CU) when there are enough 32-row query blocks to give every
-  // SIMD two waves that way; else 2 x 2 (64 rows, two key halves).  Both request the K fragments of the next tile across
-  // the barrier (four stages of the shared image).  Measured on MI355X at B16 H4 (tests/kbench/attn_bench time):
-  // Sq800 Sk800 30.4 vs 34.9 us, Sq256 Sk800 20.2 vs 14.3 us; eight waves (2 x 4) lose to 2 x 2 on every shape tried.
-  int code = g_cfg128;
-  if (code == 0) {
-    const int64_t rows32 = (int64_t)B * H * ((Sq + 31) / 32);      // 32-row query blocks
-    code = rows32 >= 1536 ? 41 : 22;
-  }
-  hipError_t e;
-  if (code == 41) e = launch_attn<DK, 4, 1, 4, true, true>(a, (hipStream_t)stream);
-  else if (code == 22) e = launch_attn<DK, 2, 2, 4, true, true>(a, (hipStream_t)stream);
-  else return -22;
-  attn_trace_dump("attn128", Sq, Sk, (hipStream_t)stream);
-  return hip_status(e);
+  return attention128_entry(Qp, ldq, X, ldx, ctx, ldo, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, g_cfg128,
+                            (hipStream_t)stream);
 }
-
 
 extern "C" int64_t bmhrl_attention_shared128_bwd_workspace(int32_t B, int32_t H, int32_t Sk) {
   return (int64_t)B * H * Sk * 128;       // fp32 elements: the per-head partials of dX

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
       if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
       else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
       static_for<0, 8>([&](auto st) {
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
+        s_acc = BMHRL_MFMA16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
         step(st);
         BMHRL_SB();
       });
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
       else if constexpr (MODE == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[8]), "+v"(kf[9]), "+v"(kf[10]), "+v"(kf[11]), "+v"(kf[12]), "+v"(kf[13]), "+v"(kf[14]), "+v"(kf[15]));
       else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[8]), "+v"(kf[9]), "+v"(kf[10]), "+v"(kf[11]), "+v"(kf[12]), "+v"(kf[13]), "+v"(kf[14]), "+v"(kf[15]));
       static_for<8, 16>([&](auto st) {
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
+        s_acc = BMHRL_MFMA16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
         step(st);
         BMHRL_SB();
       });
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
       if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
       else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
       static_for<0, 4>([&](auto st) {
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
+        s_acc = BMHRL_MFMA16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
         step(st);
         BMHRL_SB();
       });
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
       if constexpr (MODE == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
       else if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]));
       static_for<4, 8>([&](auto st) {
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
+        s_acc = BMHRL_MFMA16(kf[decltype(st)::value], qf[decltype(st)::value], s_acc, 0, 0, 0);
         step(st);
         BMHRL_SB();
       });
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
     constexpr int D0 = decltype(d0_)::value;
     static_for<0, 8>([&](auto i_) {
       constexpr int I = decltype(i_)::value;
-      o[D0 + I / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[I / 2][I % 2], pf[I % 2], o[D0 + I / 2], 0, 0, 0);
+      o[D0 + I / 2] = BMHRL_MFMA16(vf[I / 2][I % 2], pf[I % 2], o[D0 + I / 2], 0, 0, 0);
       step(i_);
       BMHRL_SB();
     });
@@ -861,4 +861,74 @@ hipError_t launch_attn(AttnArgs a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---- entry bodies shared by the bf16 and the fp16 translation units (the extern "C" symbols differ, the kernels do not).
+// Templates, so that a translation unit only instantiates the kernels of the entry it defines.
+template <int UNUSED = 0>
+int attention256_entry(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
+                              int64_t ldo, float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
+                              int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t dk, float scale,
+                              float dropout_p, uint64_t seed, const uint64_t* seed_dev, int code, hipStream_t stream) {
+  constexpr int DK = 256;
+  BMHRL_CHECK_ARG(Q && K && V && O && row_max && row_sum);
+  BMHRL_CHECK_ARG(dk == DK);  // d_model 1024 / H 4 of the reference; other head sizes use the materialised path
+  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
+  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0);
+  BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldk >= (int64_t)H * DK && ldv >= (int64_t)H * DK && ldo >= (int64_t)H * DK);
+  BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0);
+  BMHRL_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
+  BMHRL_CHECK_ARG((int64_t)Sk * ldk * 2 < (1ll << 31) && (int64_t)Sk * ldv * 2 < (1ll << 31));   // 32-bit lane offsets
+  AttnArgs a;
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+  a.O = (bf16_t*)O; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
+  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed; a.seed_dev = seed_dev;
+  a.k_hs = DK; a.v_hs = DK;
+  a.dbg = g_attn_dbg;
+  // 4 x 1 (128 query rows per workgroup, every wave sees every key: no merge, K fragments requested across the barrier)
+  // as soon as that gives most CUs a workgroup; else 2 x 2 (64 rows, two key halves).  Measured on MI355X at B16 H4
+  // (tests/kbench/attn_bench time): Sq800 Sk256 35.0 vs 47.5 us, Sq256 Sk256 17.4 vs 14.4 us, Sq256 Sk800 36 vs 28 us.
+  if (code == 0) code = ((int64_t)B * H * ((Sq + 127) / 128) >= 200) ? 41 : 22;
+  hipError_t e;
+  if (code == 41) e = launch_attn<DK, 4, 1, 3, false, true>(a, stream);
+  else if (code == 22) e = launch_attn<DK, 2, 2, 2, false, false>(a, stream);
+  else return -22;
+  attn_trace_dump("attn256", Sq, Sk, stream);
+  return hip_status(e);
+}
+
+template <int UNUSED = 0>
+int attention128_entry(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo, float* row_max,
+                              float* row_sum, const uint8_t* mask, int64_t mask_sb, int32_t B, int32_t H, int32_t Sq,
+                              int32_t Sk, float scale, int code, hipStream_t stream) {
+  constexpr int DK = 128;
+  BMHRL_CHECK_ARG(Qp && X && ctx && row_max && row_sum);
+  BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
+  BMHRL_CHECK_ARG(ldq % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0);
+  BMHRL_CHECK_ARG(ldq >= (int64_t)H * DK && ldx >= DK && ldo >= (int64_t)H * DK);
+  BMHRL_CHECK_ARG((((uintptr_t)Qp | (uintptr_t)X | (uintptr_t)ctx) & 15) == 0);
+  BMHRL_CHECK_ARG((int64_t)Sk * ldx * 2 < (1ll << 31));
+  AttnArgs a;
+  a.Q = (const bf16_t*)Qp; a.ldq = ldq; a.K = (const bf16_t*)X; a.ldk = ldx; a.V = (const bf16_t*)X; a.ldv = ldx;
+  a.O = (bf16_t*)ctx; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum;
+  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = 0;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.dropout_p = 0.f; a.seed = 0; a.seed_dev = nullptr;
+  a.k_hs = 0; a.v_hs = 0;                       // one 128-wide key / value row for every head
+  a.dbg = g_attn_dbg;
+  // 4 x 1 (128 query rows per workgroup, two workgroups per CU) when there are enough 32-row query blocks to give every
+  // SIMD two waves that way; else 2 x 2 (64 rows, two key halves).  Both request the K fragments of the next tile across
+  // the barrier (four stages of the shared image).  Measured on MI355X at B16 H4 (tests/kbench/attn_bench time):
+  // Sq800 Sk800 30.4 vs 34.9 us, Sq256 Sk800 20.2 vs 14.3 us; eight waves (2 x 4) lose to 2 x 2 on every shape tried.
+  if (code == 0) {
+    const int64_t rows32 = (int64_t)B * H * ((Sq + 31) / 32);      // 32-row query blocks
+    code = rows32 >= 1536 ? 41 : 22;
+  }
+  hipError_t e;
+  if (code == 41) e = launch_attn<DK, 4, 1, 4, true, true>(a, stream);
+  else if (code == 22) e = launch_attn<DK, 2, 2, 4, true, true>(a, stream);
+  else return -22;
+  attn_trace_dump("attn128", Sq, Sk, stream);
+  return hip_status(e);
+}
+
 }  // namespace
+

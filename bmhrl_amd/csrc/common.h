@@ -3,10 +3,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit MFMA operand type.  Every translation unit but two uses bfloat16; attention_f16.hip / attention128_f16.hip define
+// BMHRL_F16_OPERANDS and get the SAME attention kernels with IEEE half operands (BASELINE configs[4]: "fp16/bf16 MFMA
+// cross-attention"): the kernels only move 16-bit elements, hand them to the MFMA of the matching type (BMHRL_MFMA16) and
+// convert fp32 -> operand type where P and the output are formed, so the type names below are the only switch.
+#ifdef BMHRL_F16_OPERANDS
+typedef _Float16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
+#define BMHRL_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define BMHRL_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;

@@ -71,7 +71,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
 def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, ldo,
                   q_off=0, k_off=0, v_off=0, dropout_p=0.0, seed=0, seed_dev=None):
     _need_cuda(Q, K, V, O)
-    _lib.check(_lib.load().bmhrl_attention_fwd(Q.data_ptr() + 2 * q_off, ldq, K.data_ptr() + 2 * k_off, ldk,
+    f16 = Q.dtype == torch.float16          # IEEE-half operands: the fp16 build of the same kernel
+    if any((t.dtype == torch.float16) != f16 for t in (K, V, O)):
+        raise RuntimeError("attention_fwd: Q, K, V and O must share one 16-bit type")
+    fn = _lib.load().bmhrl_attention_fwd_f16 if f16 else _lib.load().bmhrl_attention_fwd
+    _lib.check(fn(Q.data_ptr() + 2 * q_off, ldq, K.data_ptr() + 2 * k_off, ldk,
                                                V.data_ptr() + 2 * v_off, ldv, O.data_ptr(), ldo, row_max.data_ptr(),
                                                row_sum.data_ptr(), _p(mask), mask_sb, mask_sq, B, H, Sq, Sk, dk, scale,
                                                dropout_p, seed, _p(seed_dev), stream()), "bmhrl_attention_fwd")
@@ -80,7 +84,11 @@ def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq
 def attention_shared128_fwd(Qp, X, ctx, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, ldq, ldx, ldo):
     """absorbed-projection attention: Qp (B,Sq,H,128), X (B,Sk,128) shared by all heads -> ctx (B,Sq,H,128)"""
     _need_cuda(Qp, X, ctx)
-    _lib.check(_lib.load().bmhrl_attention_shared128_fwd(Qp.data_ptr(), ldq, X.data_ptr(), ldx, ctx.data_ptr(), ldo,
+    f16 = Qp.dtype == torch.float16
+    if any((t.dtype == torch.float16) != f16 for t in (X, ctx)):
+        raise RuntimeError("attention_shared128_fwd: Qp, X and ctx must share one 16-bit type")
+    fn = _lib.load().bmhrl_attention_shared128_fwd_f16 if f16 else _lib.load().bmhrl_attention_shared128_fwd
+    _lib.check(fn(Qp.data_ptr(), ldq, X.data_ptr(), ldx, ctx.data_ptr(), ldo,
                                                          row_max.data_ptr(), row_sum.data_ptr(), _p(mask), mask_sb,
                                                          B, H, Sq, Sk, scale, stream()), "bmhrl_attention_shared128_fwd")
 

@@ -94,6 +94,17 @@ int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const void* X, in
                                   float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
                                   int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale, bmhrl_stream_t stream);
 
+/* IEEE-half (fp16) operand variants of the two forward entry points: Q / K / V / X / Qp in, O / ctx out are _Float16 instead
+ * of bfloat16 (v_mfma_f32_32x32x16_f16; scores, softmax statistics and accumulation stay fp32); every other argument as
+ * above.  BASELINE configs[4] names "fp16/bf16 MFMA cross-attention"; the training path of this package uses bf16. */
+int bmhrl_attention_fwd_f16(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                            void* O, int64_t ldo, float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
+                            int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t DK, float scale,
+                            float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
+int bmhrl_attention_shared128_fwd_f16(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo,
+                                      float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb,
+                                      int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale, bmhrl_stream_t stream);
+
 /* Fused backward of bmhrl_attention_shared128_fwd (autograd of attention(), model/multihead_attention.py:7-31, in the
  * absorbed-projection form): given dCx (B,Sq,H,128) bf16, the forward's statistics and delta[b,h,q] = sum_d dCx*Cx
  * (bmhrl_attn_delta), writes dQp (B,Sq,H,128) bf16 and -- when dX != NULL -- dX (B,Sk,128) fp32 (leading dim lddx; += when
