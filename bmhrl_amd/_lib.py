@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("rowvec", ptr), ("rowvec2", ptr), ("rv_sb1", i64), ("rv_sb2", i64),
         ("aux", ptr), ("ldaux", i64), ("aux_sb1", i64), ("aux_sb2", i64),
         ("dropout_p", f32), ("seed", u64), ("drop_sb1", i64), ("drop_sb2", i64), ("drop_sm", i64), ("seed_dev", ptr),
-        ("colsum", ptr), ("colsum_sb2", i64), ("bias_sb2", i64),
+        ("colsum", ptr), ("colsum_sb2", i64), ("bias_sb2", i64), ("colsum_sb1", i64), ("bias_sb1", i64),
     ]
 
 
@@ -63,6 +63,7 @@ PROTOTYPES = {
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
     "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_cast_colsum_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, ptr],
+    "bmhrl_cast_colsum_bf16_groups": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, i64, i64, ptr],
     "bmhrl_cast_segments": [ptr, i32, i32, ptr],
     "bmhrl_colsum_bf16": [ptr, i64, ptr, i32, i64, i32, ptr],
     "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],

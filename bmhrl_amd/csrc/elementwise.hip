@@ -393,12 +393,18 @@ __global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg)
 // 128-wide audio stream: cgs = 32, 8 row lanes) keeps all threads busy; one atomic per column per block.
 __global__ void cast_colsum_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows, int cols,
                                    float scale, float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev,
-                                   float* __restrict__ colsum, int rows_per_block, int cgs) {
+                                   float* __restrict__ colsum, int rows_per_block, int cgs, long group_rows, int blocks_per_group,
+                                   long cs_stride) {
+  // rows come in groups of `group_rows` with their own column-sum vector (colsum + group * cs_stride): two layers' dY in one
+  // buffer; a block never straddles two groups.  One group = the plain form.
   __shared__ float red[1024];                       // [row lane][4 * cgs]
   const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
   const int cg = threadIdx.x % cgs, ry = threadIdx.x / cgs, rl = 256 / cgs;
   const int col = blockIdx.x * 256 + cg * 4;
-  const long r0 = (long)blockIdx.y * rows_per_block;
+  const int grp = (int)blockIdx.y / blocks_per_group;
+  const long r0 = grp * group_rows + (long)((int)blockIdx.y - grp * blocks_per_group) * rows_per_block;
+  rows = (grp + 1) * group_rows < rows ? (grp + 1) * group_rows : rows;
+  colsum += grp * cs_stride;
   const bool vec = (ldx & 3) == 0 && (ldy & 3) == 0 && col + 4 <= cols && (((uintptr_t)x & 15) | ((uintptr_t)y & 7)) == 0;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (col < cols) {
@@ -797,10 +803,23 @@ extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy
   return hip_status(hipGetLastError());
 }
 
+extern "C" int bmhrl_cast_colsum_bf16_groups(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols,
+                                             float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                             float* colsum, int64_t group_rows, int64_t colsum_stride, bmhrl_stream_t stream);
+
 extern "C" int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
                                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* colsum,
                                       bmhrl_stream_t stream) {
-  BMHRL_CHECK_ARG(x && y && colsum && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
+  return bmhrl_cast_colsum_bf16_groups(x, ldx, y, ldy, rows, cols, scale, dropout_p, seed, seed_dev, colsum, rows, 0, stream);
+}
+
+extern "C" int bmhrl_cast_colsum_bf16_groups(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows_all, int32_t cols,
+                                             float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                             float* colsum, int64_t group_rows, int64_t colsum_stride, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && y && colsum && rows_all > 0 && cols > 0 && ldy >= cols && ldx >= cols);
+  BMHRL_CHECK_ARG(group_rows > 0 && rows_all % group_rows == 0);
+  const int groups = (int)(rows_all / group_rows);
+  const int64_t rows = group_rows;                     // the block shape is chosen per group
   const int col_blocks = (cols + 255) / 256;
   // ~512 blocks in total, but at most 128 row blocks: every block ends with one atomic per column, and atomics onto the
   // same address serialise (a 128-wide matrix cut into 512 row blocks spent 13 of its 16 us there)
@@ -808,11 +827,12 @@ extern "C" int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int6
   row_blocks = row_blocks < 1 ? 1 : (row_blocks > 128 ? 128 : row_blocks);
   int rpb = (int)((rows + row_blocks - 1) / row_blocks);
   if (rpb < 16) rpb = 16;
-  dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  const int bpg = (int)((rows + rpb - 1) / rpb);
+  dim3 grid((unsigned)col_blocks, (unsigned)(bpg * groups)), block(256);
   int cgs = 64;                                         // column groups per block: the smallest power of two covering it
   while (cgs > 1 && (cgs / 2) * 4 >= (cols < 256 ? cols : 256)) cgs /= 2;
-  hipLaunchKernelGGL(cast_colsum_kernel, grid, block, 0, S_(stream), x, (long)ldx, (bf16_t*)y, (long)ldy, (long)rows, cols,
-                     scale, dropout_p, seed, seed_dev, colsum, rpb, cgs);
+  hipLaunchKernelGGL(cast_colsum_kernel, grid, block, 0, S_(stream), x, (long)ldx, (bf16_t*)y, (long)ldy, (long)rows_all, cols,
+                     scale, dropout_p, seed, seed_dev, colsum, rpb, cgs, (long)group_rows, bpg, (long)colsum_stride);
   return hip_status(hipGetLastError());
 }
 
@@ -905,5 +925,5 @@ extern "C" int bmhrl_adam_segments(const int64_t* segments, int32_t n_segments, 
 extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 2: bmhrl_gemm_desc.colsum, bmhrl_cast_colsum_bf16, bmhrl_cast_segments
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
-// 7: bmhrl_adam_segments
-extern "C" int bmhrl_hip_abi_version(void) { return 7; }
+// 7: bmhrl_adam_segments   8: bmhrl_gemm_desc.colsum_sb1 / bias_sb1, fp16 attention entry points
+extern "C" int bmhrl_hip_abi_version(void) { return 8; }

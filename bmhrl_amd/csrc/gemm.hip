@@ -31,7 +31,7 @@ struct GemmArgs {
   const float* rowvec; const float* rowvec2; long rv_sb1, rv_sb2;
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
-  float* colsum; long cs_sb2, bias_sb2;
+  float* colsum; long cs_sb2, bias_sb2, cs_sb1, bias_sb1;
   int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16, fast_pd;
 };
 
@@ -58,7 +58,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     constexpr int SCB = BN + 8;
     bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
     bf16_t* __restrict__ Cbf = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2;
-    const float* __restrict__ bp = p.bias ? p.bias + b2 * p.bias_sb2 : nullptr;
+    const float* __restrict__ bp = p.bias ? p.bias + b1 * p.bias_sb1 + b2 * p.bias_sb2 : nullptr;
     const uint64_t seedf = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
     const uint64_t dbase = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
     auto stage_bf16 = [&](const f32x16& av, const int mi, const int ni) {
@@ -208,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
   const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
   const bool first_split = blockIdx.y == 0;
-  const float* __restrict__ biasp = (first_split && p.bias) ? p.bias + b2 * p.bias_sb2 : nullptr;
+  const float* __restrict__ biasp = (first_split && p.bias) ? p.bias + b1 * p.bias_sb1 + b2 * p.bias_sb2 : nullptr;
   if (!first_split) Rg = nullptr;
 
   // element-wise part, one variant per epilogue kind (KIND: 0 plain linear, 1 linear with mask / dropout, 2 PROB,
@@ -240,7 +240,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   // optional column sums of the OUTPUT tile (the bias gradient of the layer whose dY this GEMM produces): a thread
   // always works on the same 4 columns (256 % (BN/4) == 0), so it keeps a private partial and the 256 / (BN/4) threads
   // sharing a column group are combined through LDS: one atomic per column per tile
-  float* __restrict__ CSg = p.colsum ? p.colsum + b2 * p.cs_sb2 : nullptr;
+  float* __restrict__ CSg = p.colsum ? p.colsum + b1 * p.cs_sb1 + b2 * p.cs_sb2 : nullptr;
   f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
   auto run = [&](auto kind) {
 #pragma unroll 4
@@ -847,7 +847,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.aux = (const bf16_t*)d->aux; a.ldaux = d->ldaux; a.aux_sb1 = d->aux_sb1; a.aux_sb2 = d->aux_sb2;
   a.dropout_p = d->dropout_p; a.seed = d->seed; a.seed_dev = d->seed_dev; a.tiles_m = 0;
   a.drop_sb1 = d->drop_sb1; a.drop_sb2 = d->drop_sb2; a.drop_sm = d->drop_sm;
-  a.colsum = d->colsum; a.cs_sb2 = d->colsum_sb2; a.bias_sb2 = d->bias_sb2;
+  a.colsum = d->colsum; a.cs_sb2 = d->colsum_sb2; a.bias_sb2 = d->bias_sb2; a.cs_sb1 = d->colsum_sb1; a.bias_sb1 = d->bias_sb1;
   if (a.drop_sb1 == 0 && a.drop_sb2 == 0 && a.drop_sm == 0) {
     a.drop_sm = d->N; a.drop_sb2 = (long)d->M * d->N; a.drop_sb1 = a.drop_sb2 * d->batch2;
   }
@@ -857,7 +857,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.vec_ok = al(d->C, 16) && d->ldc % 4 == 0 && d->c_sb1 % 4 == 0 && d->c_sb2 % 4 == 0 && al(d->Cb, 8) && d->ldcb % 4 == 0 &&
              d->cb_sb1 % 4 == 0 && d->cb_sb2 % 4 == 0 && al(d->residual, 16) && d->ldr % 4 == 0 && d->r_sb1 % 4 == 0 &&
              d->r_sb2 % 4 == 0 && al(d->aux, 8) && d->ldaux % 4 == 0 && d->aux_sb1 % 4 == 0 && d->aux_sb2 % 4 == 0 &&
-             al(d->bias, 16) && d->bias_sb2 % 4 == 0;
+             al(d->bias, 16) && d->bias_sb2 % 4 == 0 && d->bias_sb1 % 4 == 0;
   a.fast_bf16 = d->Cb && !d->C && d->epilogue == BMHRL_EPI_LINEAR && !d->mask && !d->residual && !d->aux && !d->colsum &&
                 !d->accumulate && al(d->Cb, 16) && d->ldcb % 8 == 0 && d->cb_sb1 % 8 == 0 && d->cb_sb2 % 8 == 0;
   const bool out_ok = d->Cb && !d->C && !d->residual && !d->colsum && !d->accumulate && !d->bias && al(d->Cb, 16) &&

@@ -198,16 +198,19 @@ class StepScratch:
         self.off += n4
         return t
 
-    def memo_bf16(self, t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
-        """bf16 (rows, pad8(cols)) copy of the fp32 tensor t; inside a step the copy is made once per distinct tensor
+    def memo_bf16(self, t: torch.Tensor, rows: int, cols: int, copies: int = 1) -> torch.Tensor:
+        """bf16 (copies * rows, pad8(cols)) copy of the fp32 tensor t (laid out `copies` times back to back: the paired
+        fusion stacks address the memory as 2 B samples); inside a step the copy is made once per distinct tensor
         (the encoder memory is read by every fusion layer of both stacks)."""
-        key = (t.data_ptr(), t._version, rows, cols)
+        key = (t.data_ptr(), t._version, rows, cols, copies)
         if self.armed:
             hit = self.memo.get(key)
             if hit is not None and hit[0]() is t:
                 return hit[1]
-        buf = self.bf16(rows, cols, t.device)
-        ops.cast_bf16(t.contiguous(), cols, buf, buf.shape[1], rows, cols)
+        buf = self.bf16(copies * rows, cols, t.device)
+        tc = t.contiguous()
+        for c in range(copies):
+            ops.cast_bf16(tc, cols, buf[c * rows:], buf.shape[1], rows, cols)
         if self.armed:
             self.memo[key] = (weakref.ref(t), buf)
         return buf
@@ -690,6 +693,310 @@ class MemAttnFn(torch.autograd.Function):
         dlnb = SCRATCH.f32(dq, device=dev) if need[3] else None
         ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy, dlnw, dlnb, rows, dq)
         return (dx, dmem, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None)
+
+
+class PairMemAttnFn(torch.autograd.Function):
+    """MemAttnFn for TWO attention modules of the same shape at once: the worker and the manager fusion stacks
+    (model/bm_hrl_agent.py:523,528) run identical layers on different weights over the same encoder memory, and at 30 caption
+    positions every one of their ~50 launches per attention is bound by latency, not by work.  x2 is (2, B, L, dq), the
+    weights of the two modules are used through stacked bf16 shadows ([w_a; w_b]), and each product runs as ONE launch with the
+    pair as a GEMM batch dimension (weights: batch stride N * ld; activations: B * L rows) or, where no weight is involved
+    (scores, probabilities, context, softmax), as a batch of 2 B samples.  The memory is the same for both (for a self
+    attention it is each half's own LN(x)); its bf16 copy is laid out twice so that sample index 2 B addresses it.
+    Arithmetic per element is the one of MemAttnFn (same kernels, same epilogues, same dropout element ids per half up to the
+    half's offset).  Argument order: x2, mem, mask, H, p_drop, then the ten parameters (ln_w, ln_b, wq, bq, wk, bk, wv, bv,
+    wo, bo) of module a, then of module b."""
+
+    @staticmethod
+    def forward(ctx, x2, mem, mask, H, p_drop, *params):
+        pa, pb = params[:10], params[10:]
+        ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = zip(pa, pb)
+        dev = x2.device
+        _, B, L, dq = x2.shape
+        self_att = mem is None
+        Sk, dm = (L, dq) if self_att else mem.shape[1:]
+        D = wq[0].shape[0]
+        dk = D // H
+        R, B2 = B * L, 2 * B
+        x2 = x2.contiguous()
+        ldx, dmp, Skp = pad8(dq), pad8(dm), pad8(Sk)
+        scale = 1.0 / math.sqrt(dk)
+        xb = SCRATCH.bf16(2 * R, dq, dev)
+        mean = torch.empty(2 * R, device=dev)
+        rstd = torch.empty(2 * R, device=dev)
+        for i in range(2):
+            ops.layernorm_fwd(x2[i], ln_w[i].detach(), ln_b[i].detach(), xb[i * R:], ldx, None, mean[i * R:], rstd[i * R:], R, dq)
+        s_attn, s_res = SEEDS.next(), SEEDS.next()
+        w_q, w_k, w_v, w_o = SHADOWS.weight(*wq), SHADOWS.weight(*wk), SHADOWS.weight(*wv), SHADOWS.weight(*wo)
+        Qb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
+        ops.gemm(xb, w_q, R, D, dq, lda=ldx, ldb=w_q.shape[1], batch=(1, 2), a_strides=(0, R * ldx), b_strides=(0, D * w_q.shape[1]),
+                 C_bf16=Qb, ldcb=D, cb_strides=(0, R * D), bias=SHADOWS.bias(*bq), bias_sb2=D)
+        memb = xb if self_att else SCRATCH.memo_bf16(mem, B * Sk, dm, copies=2)
+        zeros = torch.zeros if dmp != dm else torch.empty
+        Qp = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        ldk = w_k.shape[1]
+        ops.gemm(Qb, w_k, R, dm, dk, lda=D, ldb=ldk, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
+                 b_strides=(D * ldk, dk * ldk), C_bf16=Qp, ldcb=H * dmp, cb_strides=(R * H * dmp, dmp))
+        m8, msb, msq = _mask_u8(mask)            # the caller passes the mask of 2 B samples
+        assert m8 is None or m8.shape[0] == B2
+        Cx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        S = torch.empty(B2, L, H, Skp, device=dev)
+        ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B2, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
+                 C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb, mask_sm=msq)
+        P = _padded_bf16(B2 * L * H, Sk, dev).view(B2, L, H, Skp)
+        ops.softmax_rows(S, Skp, P, Skp, B2 * L * H, Sk)
+        ops.gemm(P, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=(L * H * Skp, Skp),
+                 b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        Ob = torch.empty(2 * R, D, dtype=_BF16, device=dev)
+        ldv = w_v.shape[1]
+        ops.gemm(Cx, w_v, R, dk, dm, lda=H * dmp, ldb=ldv, batch=(2, H), a_strides=(R * H * dmp, dmp), b_strides=(D * ldv, dk * ldv),
+                 C_bf16=Ob, ldcb=D, cb_strides=(R * D, dk), bias=SHADOWS.bias(*bv), bias_sb1=D, bias_sb2=dk,
+                 dropout_p=p_drop, seed=s_attn, seed_dev=SEEDS.dev, drop_strides=(R * D, dk, D))
+        y = torch.empty(2, B, L, dq, device=dev)
+        ops.gemm(Ob, w_o, R, dq, D, lda=D, ldb=w_o.shape[1], batch=(1, 2), a_strides=(0, R * D), b_strides=(0, dq * w_o.shape[1]),
+                 C_f32=y, ldc=dq, c_strides=(0, R * dq), bias=SHADOWS.bias(*bo), bias_sb2=dq, residual=x2, ldr=dq,
+                 r_strides=(0, R * dq), dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, drop_strides=(0, R * dq, dq))
+        ctx.save_for_backward(x2, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, m8, P, *params)
+        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy2):
+        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq = ctx.cfg
+        x2, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, m8, P = ctx.saved_tensors[:11]
+        params = ctx.saved_tensors[11:]
+        ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = zip(params[:10], params[10:])
+        dev = dy2.device
+        R, B2 = B * L, 2 * B
+        ldx, dmp, Skp = pad8(dq), pad8(dm), pad8(Sk)
+        scale = 1.0 / math.sqrt(dk)
+        need = ctx.needs_input_grad
+        dy2 = dy2.contiguous()
+        w_q, w_k, w_v, w_o = SHADOWS.weight(*wq), SHADOWS.weight(*wk), SHADOWS.weight(*wv), SHADOWS.weight(*wo)
+        ldk, ldv = w_k.shape[1], w_v.shape[1]
+        zeros = torch.zeros if dmp != dm else torch.empty
+        # out projection: dWo, dbo (column sums of the cast, one vector per half); d(attention output) through its dropout
+        dyb = SCRATCH.bf16(2 * R, dq, dev)
+        dbo = SCRATCH.f32(2 * dq, device=dev)
+        ops.cast_colsum_bf16(dy2, dq, dyb, ldx, 2 * R, dq, dbo, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, group_rows=R,
+                             colsum_stride=dq)
+        dwo = SCRATCH.f32(2 * dq, D, device=dev)
+        ops.gemm(dyb, Ob, dq, D, R, lda=ldx, ldb=D, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
+                 b_strides=(0, R * D), C_f32=dwo, ldc=D, c_strides=(0, dq * D), allow_split_k=True)
+        dOb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
+        dbv = SCRATCH.f32(2 * D, device=dev)
+        ops.gemm(dyb, w_o, R, D, dq, lda=ldx, ldb=w_o.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
+                 b_strides=(0, dq * w_o.shape[1]), C_bf16=dOb, ldcb=D, cb_strides=(0, R * D), dropout_p=p_drop, seed=s_attn,
+                 seed_dev=SEEDS.dev, drop_strides=(0, R * D, D), colsum=dbv, colsum_sb2=D)
+        # O_h = Cx_h Wv_h^T + bv_h
+        dwv = SCRATCH.f32(2 * D, dm, device=dev)
+        ops.gemm(dOb, Cx, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
+                 b_strides=(R * H * dmp, dmp), C_f32=dwv, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
+        dCx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        ops.gemm(dOb, w_v, R, dm, dk, lda=D, ldb=ldv, b_trans=True, batch=(2, H), a_strides=(R * D, dk), b_strides=(D * ldv, dk * ldv),
+                 C_bf16=dCx, ldcb=H * dmp, cb_strides=(R * H * dmp, dmp))
+        delta = torch.empty(B2, H, L, device=dev)
+        ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B2, H, L, dmp)
+        dS = _padded_bf16(B2 * L * H, Sk, dev).view(B2, L, H, Skp)
+        pstr = (L * H * Skp, Skp)
+        ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B2, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
+                 C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
+                 rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
+
+        def grad_mem(target, first_accumulates):      # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h, b over the 2 B samples
+            ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B2, 1),
+                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
+                     accumulate=first_accumulates)
+            ops.gemm(dS, Qp, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B2, 1),
+                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
+                     accumulate=True)
+        dmem = None
+        if need[1] and not self_att:
+            dmem2 = torch.empty(B2, Sk, dm, device=dev)
+            grad_mem(dmem2, False)
+            dmem = dmem2[:B] + dmem2[B:]                # both halves read the same memory
+        dQp = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
+                 C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        # Q'_h = Q_h Wk_h
+        dwk = SCRATCH.f32(2 * D, dm, device=dev)
+        ops.gemm(Qb, dQp, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
+                 b_strides=(R * H * dmp, dmp), C_f32=dwk, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
+        dbq = SCRATCH.f32(2 * D, device=dev)
+        dQb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
+        ops.gemm(dQp, w_k, R, dk, dm, lda=H * dmp, ldb=ldk, batch=(2, H), a_strides=(R * H * dmp, dmp), b_strides=(D * ldk, dk * ldk),
+                 C_bf16=dQb, ldcb=D, cb_strides=(R * D, dk), colsum=dbq, colsum_sb1=D, colsum_sb2=dk)
+        dbk = SCRATCH.f32(2 * D, device=dev)            # exactly zero: a shift of all keys' scores
+        # Q projection and LayerNorm
+        dwq = SCRATCH.f32(2 * D, dq, device=dev)
+        ops.gemm(dQb, xb, D, dq, R, lda=D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * D),
+                 b_strides=(0, R * ldx), C_f32=dwq, ldc=dq, c_strides=(0, D * dq), allow_split_k=True)
+        dxn = torch.empty(2 * R, dq, device=dev)
+        ops.gemm(dQb, w_q, R, dq, D, lda=D, ldb=w_q.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * D),
+                 b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq))
+        if self_att:
+            grad_mem(dxn, True)                         # the keys / values are LN(x) too
+        dx2 = torch.empty(2, B, L, dq, device=dev)
+        dln = []
+        for i in range(2):
+            dlnw, dlnb = SCRATCH.f32(dq, device=dev), SCRATCH.f32(dq, device=dev)
+            ops.layernorm_bwd(dxn[i * R:], x2[i], ln_w[i], mean[i * R:], rstd[i * R:], dx2[i], dy2[i], dlnw, dlnb, R, dq)
+            dln.append((dlnw, dlnb))
+        out = []
+        for i in range(2):
+            g = (dln[i][0], dln[i][1], dwq[i * D:(i + 1) * D], dbq[i * D:(i + 1) * D], dwk[i * D:(i + 1) * D], dbk[i * D:(i + 1) * D],
+                 dwv[i * D:(i + 1) * D], dbv[i * D:(i + 1) * D], dwo[i * dq:(i + 1) * dq], dbo[i * dq:(i + 1) * dq])
+            out += [gi if need[5 + 10 * i + j] else None for j, gi in enumerate(g)]
+        return (dx2, dmem, None, None, None, *out)
+
+
+class PairSelfAttnFn(torch.autograd.Function):
+    """MHAFn's self-attention branch (x + dropout(d2Q(attention(Q2d, K2d, V2d of LN(x))))) for the two fusion stacks at once:
+    the projections run with the pair as a GEMM batch dimension over stacked weights ([q_a; k_a; v_a; q_b; k_b; v_b]), the
+    attention core over 2 B samples.  Same kernels and the same projected form as the single-stack call (the caption self
+    attention has as many keys as queries: absorbing the projections would only add launches).  Arguments: x2 (2, B, L, dq),
+    mask of 2 B samples, H, p_drop, then (ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo) of module a and of module b."""
+
+    @staticmethod
+    def forward(ctx, x2, mask, H, p_drop, *params):
+        ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = zip(params[:10], params[10:])
+        dev = x2.device
+        _, B, L, dq = x2.shape
+        D = wq[0].shape[0]
+        dk = D // H
+        R, B2 = B * L, 2 * B
+        x2 = x2.contiguous()
+        ldx = pad8(dq)
+        xb = SCRATCH.bf16(2 * R, dq, dev)
+        mean = torch.empty(2 * R, device=dev)
+        rstd = torch.empty(2 * R, device=dev)
+        for i in range(2):
+            ops.layernorm_fwd(x2[i], ln_w[i].detach(), ln_b[i].detach(), xb[i * R:], ldx, None, mean[i * R:], rstd[i * R:], R, dq)
+        s_attn, s_res = SEEDS.next(), SEEDS.next()
+        w_qkv = SHADOWS.weight(wq[0], wk[0], wv[0], wq[1], wk[1], wv[1])
+        b_qkv = SHADOWS.bias(bq[0], bk[0], bv[0], bq[1], bk[1], bv[1])
+        QKV = torch.empty(2 * R, 3 * D, dtype=_BF16, device=dev)
+        ops.gemm(xb, w_qkv, R, 3 * D, dq, lda=ldx, ldb=w_qkv.shape[1], batch=(1, 2), a_strides=(0, R * ldx),
+                 b_strides=(0, 3 * D * w_qkv.shape[1]), C_bf16=QKV, ldcb=3 * D, cb_strides=(0, R * 3 * D), bias=b_qkv, bias_sb2=3 * D)
+        m8, msb, msq = _mask_u8(mask)
+        assert m8 is None or m8.shape[0] == B2
+        Ob, stats = _attn_core_fwd(QKV, 0, 3 * D, QKV, D, 3 * D, QKV, 2 * D, 3 * D, m8, msb, msq, B2, H, L, L, dk, p_drop, s_attn)
+        assert stats[0] == "mat"
+        w_o = SHADOWS.weight(*wo)
+        y = torch.empty(2, B, L, dq, device=dev)
+        ops.gemm(Ob, w_o, R, dq, D, lda=D, ldb=w_o.shape[1], batch=(1, 2), a_strides=(0, R * D), b_strides=(0, dq * w_o.shape[1]),
+                 C_f32=y, ldc=dq, c_strides=(0, R * dq), bias=SHADOWS.bias(*bo), bias_sb2=dq, residual=x2, ldr=dq,
+                 r_strides=(0, R * dq), dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, drop_strides=(0, R * dq, dq))
+        ctx.save_for_backward(x2, mean, rstd, xb, QKV, Ob, m8, stats[1], *params)
+        ctx.cfg = (B, L, dq, D, H, dk, p_drop, s_attn, s_res, msb, msq)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy2):
+        B, L, dq, D, H, dk, p_drop, s_attn, s_res, msb, msq = ctx.cfg
+        x2, mean, rstd, xb, QKV, Ob, m8, P = ctx.saved_tensors[:8]
+        params = ctx.saved_tensors[8:]
+        ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = zip(params[:10], params[10:])
+        dev = dy2.device
+        R, B2 = B * L, 2 * B
+        ldx = pad8(dq)
+        need = ctx.needs_input_grad
+        dy2 = dy2.contiguous()
+        dyb = SCRATCH.bf16(2 * R, dq, dev)
+        dbo = SCRATCH.f32(2 * dq, device=dev)
+        ops.cast_colsum_bf16(dy2, dq, dyb, ldx, 2 * R, dq, dbo, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, group_rows=R,
+                             colsum_stride=dq)
+        w_o = SHADOWS.weight(*wo)
+        dwo = SCRATCH.f32(2 * dq, D, device=dev)
+        ops.gemm(dyb, Ob, dq, D, R, lda=ldx, ldb=D, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
+                 b_strides=(0, R * D), C_f32=dwo, ldc=D, c_strides=(0, dq * D), allow_split_k=True)
+        dOb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
+        ops.gemm(dyb, w_o, R, D, dq, lda=ldx, ldb=w_o.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
+                 b_strides=(0, dq * w_o.shape[1]), C_bf16=dOb, ldcb=D, cb_strides=(0, R * D), dropout_p=p_drop, seed=s_attn,
+                 seed_dev=SEEDS.dev, drop_strides=(0, R * D, D))
+        dQKV = torch.empty(2 * R, 3 * D, dtype=_BF16, device=dev)
+        _attn_core_bwd(dOb, Ob, ("mat", P), QKV, 0, 3 * D, QKV, D, 3 * D, QKV, 2 * D, 3 * D, dQKV, 0, 3 * D, dQKV, D, 3 * D,
+                       dQKV, 2 * D, 3 * D, m8, msb, msq, B2, H, L, L, dk, p_drop)
+        db = SCRATCH.f32(2 * 3 * D, device=dev)           # bias gradients [q | k | v] of each half: column sums of its rows
+        for i in range(2):
+            ops.colsum_bf16(dQKV, 3 * D, db, True, R, 3 * D, dy_off=i * R * 3 * D, db_off=i * 3 * D)
+        w_qkv = SHADOWS.weight(wq[0], wk[0], wv[0], wq[1], wk[1], wv[1])
+        dw = SCRATCH.f32(2 * 3 * D, dq, device=dev)
+        ops.gemm(dQKV, xb, 3 * D, dq, R, lda=3 * D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
+                 b_strides=(0, R * ldx), C_f32=dw, ldc=dq, c_strides=(0, 3 * D * dq), allow_split_k=True)
+        dxn = torch.empty(2 * R, dq, device=dev)
+        ops.gemm(dQKV, w_qkv, R, dq, 3 * D, lda=3 * D, ldb=w_qkv.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
+                 b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq))
+        dx2 = torch.empty(2, B, L, dq, device=dev)
+        out = []
+        for i in range(2):
+            dlnw, dlnb = SCRATCH.f32(dq, device=dev), SCRATCH.f32(dq, device=dev)
+            ops.layernorm_bwd(dxn[i * R:], x2[i], ln_w[i], mean[i * R:], rstd[i * R:], dx2[i], dy2[i], dlnw, dlnb, R, dq)
+            w0, b0 = i * 3 * D, i * 3 * D
+            g = (dlnw, dlnb, dw[w0:w0 + D], db[b0:b0 + D], dw[w0 + D:w0 + 2 * D], db[b0 + D:b0 + 2 * D],
+                 dw[w0 + 2 * D:w0 + 3 * D], db[b0 + 2 * D:b0 + 3 * D], dwo[i * dq:(i + 1) * dq], dbo[i * dq:(i + 1) * dq])
+            out += [gi if need[4 + 10 * i + j] else None for j, gi in enumerate(g)]
+        return (dx2, None, None, None, *out)
+
+
+class PairRowFn(torch.autograd.Function):
+    """LayerNorm (normCA / normCV) of the two stacks' rows in one (2, B, L, D) buffer: two launches, no copies."""
+
+    @staticmethod
+    def forward(ctx, x2, wa, ba, wb, bb):
+        x2 = x2.contiguous()
+        D = x2.shape[-1]
+        R = x2[0].numel() // D
+        y = torch.empty_like(x2)
+        mean = torch.empty(2 * R, device=x2.device)
+        rstd = torch.empty(2 * R, device=x2.device)
+        for i, (w, b) in enumerate(((wa, ba), (wb, bb))):
+            ops.layernorm_fwd(x2[i], w.detach(), b.detach(), None, 0, y[i], mean[i * R:], rstd[i * R:], R, D)
+        ctx.save_for_backward(x2, wa, wb, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wa, wb, mean, rstd = ctx.saved_tensors
+        D = x2.shape[-1]
+        R = x2[0].numel() // D
+        dy = dy.contiguous()
+        dx = torch.empty_like(x2)
+        gs = []
+        for i, w in enumerate((wa, wb)):
+            dw, db = SCRATCH.f32(D, device=x2.device), SCRATCH.f32(D, device=x2.device)
+            ops.layernorm_bwd(dy[i], x2[i], w, mean[i * R:], rstd[i * R:], dx[i], None, dw, db, R, D)
+            gs += [dw, db]
+        return dx, gs[0], gs[1], gs[2], gs[3]
+
+
+class PairGateFn(torch.autograd.Function):
+    """GateFn of the two stacks' rows in one (2, B, L, D) buffer (each half with its own a_v_constant)."""
+
+    @staticmethod
+    def forward(ctx, cv2, ca2, a_va, a_vb):
+        cv2, ca2 = cv2.contiguous(), ca2.contiguous()
+        D = cv2.shape[-1]
+        R = cv2[0].numel() // D
+        out = torch.empty_like(cv2)
+        for i, a in enumerate((a_va, a_vb)):
+            ops.gate_fwd(cv2[i], ca2[i], a.detach(), out[i], None, 0, R, D)
+        ctx.save_for_backward(cv2, ca2, a_va, a_vb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cv2, ca2, a_va, a_vb = ctx.saved_tensors
+        D = cv2.shape[-1]
+        R = cv2[0].numel() // D
+        dout = dout.contiguous()
+        dcv, dca = torch.empty_like(cv2), torch.empty_like(ca2)
+        das = []
+        for i, a in enumerate((a_va, a_vb)):
+            da = SCRATCH.f32(1, device=cv2.device)
+            ops.gate_bwd(dout[i], cv2[i], ca2[i], a, dcv[i], dca[i], da, R, D)
+            das.append(da)
+        return dcv, dca, das[0], das[1]
 
 
 class AttnCoreFn(torch.autograd.Function):

@@ -6,6 +6,8 @@ fusion stacks, manager and worker runs in the gfx950 HIP kernels (bmhrl_amd.func
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -179,6 +181,42 @@ class BMFusionLayer(nn.Module):
         if kv_cache is None and self.absorb_memory_projections and C.is_cuda and torch.is_grad_enabled():
             return att.fused_memory(C, mem, mask, norm)
         return att.fused(C, mem, mask, norm, residual=True, kv_cache=kv_cache)
+
+
+def _att_params(att, norm):
+    return (norm.weight, norm.bias) + att._params()
+
+
+def fusion_pair(fw, fm, C, Av, Va, masks):
+    """Both fusion stacks (reference :523,528: same layers, different weights, same inputs) layer by layer with every
+    product of the two stacks in one launch -- see functional.PairMemAttnFn.  Same arithmetic as BMFusion.forward on each
+    stack; returns (worker features, manager features)."""
+    from ..functional import PairGateFn, PairMemAttnFn, PairRowFn, PairSelfAttnFn
+    C2 = torch.stack([C, C])                                     # (2, B, L, d_caps): stack 0 = worker, 1 = manager
+    cm2, am2, vm2 = (torch.cat([masks[k], masks[k]]) for k in ('C_mask', 'A_mask', 'V_mask'))
+    for lw, lm in zip(fw.decoder.layers, fm.decoder.layers):
+        H = lw.self_att.H
+        p = lw.self_att.dout_p if lw.training else 0.0
+        C2 = PairSelfAttnFn.apply(C2, cm2, H, p, *_att_params(lw.self_att, lw.res_layer_self_att.norm),
+                                  *_att_params(lm.self_att, lm.res_layer_self_att.norm))
+        side = None
+        if BMFusionLayer.branch_side_stream:                     # audio- and video-memory attentions as parallel branches
+            main = torch.cuda.current_stream()
+            side = BMFusionLayer._side
+            if side is None or side.device != C.device:
+                side = BMFusionLayer._side = torch.cuda.Stream(device=C.device)
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+            Ca2 = PairMemAttnFn.apply(C2, Av, am2, H, p, *_att_params(lw.enc_att_A, lw.res_layer_enc_att_A.norm),
+                                      *_att_params(lm.enc_att_A, lm.res_layer_enc_att_A.norm))
+            Ca2 = PairRowFn.apply(Ca2, lw.normCA.weight, lw.normCA.bias, lm.normCA.weight, lm.normCA.bias)
+        Cv2 = PairMemAttnFn.apply(C2, Va, vm2, H, p, *_att_params(lw.enc_att_V, lw.res_layer_enc_att_V.norm),
+                                  *_att_params(lm.enc_att_V, lm.res_layer_enc_att_V.norm))
+        Cv2 = PairRowFn.apply(Cv2, lw.normCV.weight, lw.normCV.bias, lm.normCV.weight, lm.normCV.bias)
+        if side is not None:
+            main.wait_stream(side)
+        C2 = PairGateFn.apply(Cv2, Ca2, lw.a_v_constant, lm.a_v_constant)
+    return C2[0], C2[1]
 
 
 class BMFusion(nn.Module):
@@ -450,6 +488,8 @@ class BMHrlAgent(nn.Module):
         return self.prediction(x, trg, mask)
 
     critic_side_stream = True
+    # training: layer l of the worker and of the manager fusion stack run as ONE set of launches (functional.PairMemAttnFn)
+    pair_fusion_stacks = os.environ.get("BMHRL_PAIR_STACKS", "1") == "1"
 
     def _side_stream(self, device, attr="_critic_stream"):
         st = getattr(self, attr, None)
@@ -518,8 +558,11 @@ class BMHrlAgent(nn.Module):
         Va, Av = self.bm_enc((V, A), mask) if memory is None else memory
         # (worker and manager stacks as two parallel branches were measured slower than back to back: 10.8 -> 11.4 ms/step;
         # the branches that pay off are inside the layers: BMEncoderLayer.modality_side_stream, BMFusionLayer.branch_side_stream)
-        worker_feat = self.bm_worker_fus((C, (Av, Va)), mask)
-        manager_feat = self.bm_manager_fus((C, (Av, Va)), mask)
+        if self.pair_fusion_stacks and C.is_cuda and torch.is_grad_enabled():
+            worker_feat, manager_feat = fusion_pair(self.bm_worker_fus, self.bm_manager_fus, C, Av, Va, mask)
+        else:
+            worker_feat = self.bm_worker_fus((C, (Av, Va)), mask)
+            manager_feat = self.bm_manager_fus((C, (Av, Va)), mask)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         goals = self.manager(manager_feat, segment_labels)

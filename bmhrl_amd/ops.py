@@ -44,7 +44,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
          aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False,
-         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0, bias_sb2=0) -> None:
+         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0, bias_sb2=0, colsum_sb1=0, bias_sb1=0) -> None:
     """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
     _need_cuda(A, B, C_f32, C_bf16)
     d = _lib.GemmDesc()
@@ -64,7 +64,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.dropout_p = dropout_p; d.seed = seed; d.seed_dev = _p(seed_dev)
     d.drop_sb1, d.drop_sb2, d.drop_sm = drop_strides
     d.colsum = None if colsum is None else colsum.data_ptr() + 4 * colsum_off; d.colsum_sb2 = colsum_sb2
-    d.bias_sb2 = bias_sb2
+    d.bias_sb2 = bias_sb2; d.bias_sb1 = bias_sb1; d.colsum_sb1 = colsum_sb1
     _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
 
 
@@ -160,9 +160,16 @@ def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_of
                                            seed, _p(seed_dev), stream()), "bmhrl_cast_bf16")
 
 
-def cast_colsum_bf16(x, ldx, y, ldy, rows, cols, colsum, scale=1.0, dropout_p=0.0, seed=0, seed_dev=None, colsum_off=0):
-    """y = bf16(x * scale * dropout); colsum[colsum_off + n] += column sums of y (colsum must start zeroed)"""
+def cast_colsum_bf16(x, ldx, y, ldy, rows, cols, colsum, scale=1.0, dropout_p=0.0, seed=0, seed_dev=None, colsum_off=0,
+                     group_rows=None, colsum_stride=0):
+    """y = bf16(x * scale * dropout); colsum[colsum_off + n] += column sums of y (colsum must start zeroed).
+    group_rows: the rows form groups of that many, group g adds into colsum[colsum_off + g * colsum_stride + n]"""
     _need_cuda(x, y, colsum)
+    if group_rows is not None:
+        _lib.check(_lib.load().bmhrl_cast_colsum_bf16_groups(x.data_ptr(), ldx, y.data_ptr(), ldy, rows, cols, scale, dropout_p,
+                                                             seed, _p(seed_dev), colsum.data_ptr() + 4 * colsum_off, group_rows,
+                                                             colsum_stride, stream()), "bmhrl_cast_colsum_bf16_groups")
+        return
     _lib.check(_lib.load().bmhrl_cast_colsum_bf16(x.data_ptr(), ldx, y.data_ptr(), ldy, rows, cols, scale, dropout_p, seed,
                                                   _p(seed_dev), colsum.data_ptr() + 4 * colsum_off, stream()),
                "bmhrl_cast_colsum_bf16")

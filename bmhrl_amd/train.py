@@ -56,6 +56,14 @@ class FlatAdam:
 
     fused_shadows = os.environ.get("BMHRL_FUSED_SHADOWS", "1") == "1"   # False: plain Adam kernel + a whole-cache shadow refresh at the start of the next step
 
+    def mark_uncovered_stale(self):
+        """shadow groups this optimizer changes parameters of but cannot write (see _segment_plan) must be re-cast at the
+        start of every step -- also inside a captured step, where the host-side bookkeeping of step() does not run"""
+        cached = self.__dict__.get("_seg_plan")
+        if cached is not None:
+            for kind, key in cached[1][3]:
+                SHADOWS.mark_stale(kind, key)
+
     def _segment_plan(self):
         """(table, n_segments, n_blocks, uncovered shadow entries) for ops.adam_segments, or None while it cannot be built
         (during a graph capture before a warm-up step made it).  One row per parameter in bucket order; a parameter that
@@ -71,7 +79,7 @@ class FlatAdam:
                     continue
                 mine = [id(p) in index and self.params[index[id(p)]] is p for p in params]
                 if any(mine):
-                    groups.append((kind, key, e[1], params, all(mine)))
+                    groups.append((kind, key, e[1], params, mine))
         sig = tuple((kind, key, buf.data_ptr()) for kind, key, buf, _, _ in groups)
         cached = self.__dict__.get("_seg_plan")
         if cached is not None and cached[0] == sig:
@@ -79,18 +87,23 @@ class FlatAdam:
         if torch.cuda.is_current_stream_capturing():
             return None
         dst, uncovered = {}, []
-        for kind, key, buf, params, all_mine in groups:
-            if not all_mine or any(id(p) in dst for p in params):
+        for kind, key, buf, params, mine in groups:
+            # members that are not this optimizer's (frozen parameters: the manager side in the worker phase shares the
+            # paired fusion stacks' groups with the worker side) keep the rows they have; a parameter of mine that already
+            # has a destination in another group cannot be written twice: that group is re-cast by ShadowCache.refresh()
+            if any(m and id(p) in dst for p, m in zip(params, mine)):
                 uncovered.append((kind, key))
                 continue
             off = 0
-            for p in params:
+            for p, m in zip(params, mine):
                 if kind:
                     n, kk, ld = p.shape[0], p.shape[1], buf.shape[1]
-                    dst[id(p)] = (buf.data_ptr() + 2 * off * ld, n, kk, ld)
+                    if m:
+                        dst[id(p)] = (buf.data_ptr() + 2 * off * ld, n, kk, ld)
                     off += n
                 else:
-                    dst[id(p)] = (buf.data_ptr() + 4 * off, 1, p.numel(), 0)
+                    if m:
+                        dst[id(p)] = (buf.data_ptr() + 4 * off, 1, p.numel(), 0)
                     off += p.numel()
         rows, blk = [], 0
         for p, o, sz in zip(self.params, self.offsets, self.sizes):
@@ -436,7 +449,10 @@ class CaptionTrainer:
         SEEDS.dev.add_(1)
         if not self.opt.fused_shadows:
             SHADOWS.invalidate()
-        SHADOWS.refresh()                     # (fused_shadows: the Adam pass keeps the shadows current -- nothing to do here)
+        for o in (self.opt, getattr(self, "vopt", None)):
+            if o is not None:
+                o.mark_uncovered_stale()
+        SHADOWS.refresh()                     # (fused_shadows: the Adam pass keeps the shadows current -- usually nothing to do)
         loss, _ = self._forward_loss(st, trg_in, trg_y)
         if self._split():
             # phase 0 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)

@@ -62,7 +62,8 @@ typedef struct bmhrl_gemm_desc {
   const uint64_t* seed_dev;                       /* optional device word added to seed (changes under graph replay) */
   float* colsum; int64_t colsum_sb2;              /* optional: colsum[b2*colsum_sb2 + n] += sum_m v (fp32 atomics; the bias
                                                      gradient of the layer whose dY this GEMM writes); not with split-K */
-  int64_t bias_sb2;                               /* bias of batch entry (b1, b2) starts at bias + b2*bias_sb2 (per-head bias slices) */
+  int64_t bias_sb2;                               /* bias of batch entry (b1, b2) starts at bias + b1*bias_sb1 + b2*bias_sb2 (per-head bias slices) */
+  int64_t colsum_sb1, bias_sb1;                   /* batch1 strides of colsum / bias (two weight sets in one launch: ABI 8) */
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
@@ -177,6 +178,11 @@ int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t r
  * model/multihead_attention.py:53-56 / model/blocks.py:181-182 under autograd. */
 int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
                            float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* colsum, bmhrl_stream_t stream);
+/* the same over `rows / group_rows` row groups, group g adding into colsum + g * colsum_stride (the dY of two layers in one
+ * buffer); rows % group_rows == 0.  Dropout element ids run over all rows, as in the one-group call. */
+int bmhrl_cast_colsum_bf16_groups(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
+                                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* colsum,
+                                  int64_t group_rows, int64_t colsum_stride, bmhrl_stream_t stream);
 
 /* One launch for many casts: the per-step refresh of every bf16 weight shadow / concatenated bias (what the reference
  * gets for free by computing in fp32: model/multihead_attention.py:53-56, model/blocks.py:181-182 hold fp32 weights).

@@ -331,3 +331,48 @@ def test_value_functions_match_the_reference(golden):
                     g = torch.from_numpy(z[f"d{d}/{name}/grad/{k}"])
                     err = float((v.grad.cpu() - g).norm() / g.norm().clamp_min(1e-12))
                     assert err <= 2e-2, (d, name, k, err)
+
+
+@pytest.mark.parametrize("tiny", [True, False])
+def test_paired_fusion_stacks_equal_separate_stacks(dev, tiny):
+    """functional.PairMemAttnFn (worker and manager fusion stacks in one set of launches) against the two stacks run one
+    after the other: same log-probs, features and every gradient (same kernels on the same numbers; what differs is the
+    arrival order of the fp32 atomics of split-K weight gradients and column sums)."""
+    from bmhrl_amd.loss.label_smoothing import LabelSmoothing
+    from bmhrl_amd.model.bm_hrl_agent import BMHrlAgent
+    from bmhrl_amd.model.masking import make_masks
+    if tiny:
+        cfg = syn.tiny_cfg(dout_p=0.0)
+        V, shape = 50, (4, 7, 9, 6)
+    else:
+        cfg = syn.default_cfg(dout_p=0.0)
+        V, shape = 300, (3, 96, 200, 12)
+    agent, _ = build_agent(cfg, V, dev)
+    agent.train()
+    b = syn.synthetic_batch(*shape, V, seed=11, d_vid=cfg.d_vid, d_aud=cfg.d_aud, min_len=3)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    cap = b["captions"].to(dev)
+    trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
+    masks = make_masks(fs, trg_in, "audio_video", 1)
+    crit = LabelSmoothing(0.7, 1)
+    runs = {}
+    for pair in (True, False):
+        BMHrlAgent.pair_fusion_stacks = pair
+        try:
+            agent.zero_grad()
+            out = agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
+            loss = torch.sum(crit(out[0], trg_y)) / (trg_y != 1).sum() + 1e-3 * out[2].square().sum() + 1e-3 * out[3].sum()
+            loss.backward()
+            runs[pair] = ([o.detach().float().clone() for o in out[:4]], float(loss.detach()),
+                          {n: p.grad.detach().clone() for n, p in agent.named_parameters() if p.grad is not None})
+        finally:
+            BMHrlAgent.pair_fusion_stacks = True
+    (oa, la, ga), (ob, lb, gb) = runs[True], runs[False]
+    for x, y in zip(oa, ob):
+        assert rel(x, y.cpu()) < 1e-5
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert set(ga) == set(gb) and len(ga) > 100
+    # (key biases: a shift of every key's score cancels in the softmax -- their gradient is rounding residue in both runs)
+    worst = max((float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-12)), n) for n in gb
+                if float(gb[n].norm()) > 0 and not n.endswith("linear_K2d.bias"))
+    assert worst[0] < 5e-3, worst

@@ -327,3 +327,93 @@ def test_absorbed_attention_fused_128_path(kind, B, L, Sk, dq):
             assert float(got[3][k].abs().max()) == 0.0
         else:
             assert rl2(got[3][k], ref[3][k]) < 1.5e-2, k
+
+
+@pytest.mark.parametrize("self_att,B,L,Sk,dq,dm,D,H", [(False, 3, 30, 200, 300, 128, 1024, 4), (False, 2, 30, 96, 300, 1024, 1024, 4),
+                                                       (True, 3, 30, 30, 300, 300, 1024, 4), (False, 4, 6, 9, 40, 24, 64, 4),
+                                                       (True, 4, 6, 6, 40, 40, 64, 4)])
+def test_pair_memory_attention_equals_two_single_calls(self_att, B, L, Sk, dq, dm, D, H):
+    """PairMemAttnFn on two parameter sets == MemAttnFn called once per set (outputs and every gradient)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd.functional import MemAttnFn, PairMemAttnFn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + L + dm)
+    rnd = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(dev)
+    def pset():
+        return [1 + 0.1 * rnd(dq), 0.1 * rnd(dq), rnd(D, dq, sc=dq ** -0.5), 0.1 * rnd(D), rnd(D, dm, sc=dm ** -0.5), 0.1 * rnd(D),
+                rnd(D, dm, sc=dm ** -0.5), 0.1 * rnd(D), rnd(dq, D, sc=D ** -0.5), 0.1 * rnd(dq)]
+    pa, pb = pset(), pset()
+    x2 = rnd(2, B, L, dq)
+    mem = None if self_att else rnd(B, Sk, dm)
+    if self_att:
+        mask = torch.tril(torch.ones(L, L, dtype=torch.bool, device=dev)).repeat(B, 1, 1)
+        mask[0, :, L - 2:] = False
+    else:
+        mask = torch.ones(B, 1, Sk, dtype=torch.bool, device=dev)
+        mask[1, 0, Sk - 3:] = False
+    w2 = rnd(2, B, L, dq)
+    def leaf(ts):
+        return [t.clone().requires_grad_(True) for t in ts]
+    # paired
+    xa = x2.clone().requires_grad_(True)
+    ma = mem.clone().requires_grad_(True) if mem is not None else None
+    qa, qb = leaf(pa), leaf(pb)
+    y = PairMemAttnFn.apply(xa, ma, torch.cat([mask, mask]), H, 0.0, *qa, *qb)
+    (y * w2).sum().backward()
+    # one call per parameter set
+    xs = x2.clone().requires_grad_(True)
+    ms = mem.clone().requires_grad_(True) if mem is not None else None
+    ra, rb = leaf(pa), leaf(pb)
+    ys = torch.stack([MemAttnFn.apply(xs[i], ms, *r, mask, H, 0.0) for i, r in enumerate((ra, rb))])
+    (ys * w2).sum().backward()
+    def err(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    assert err(y, ys) < 1e-6, ("y", err(y[0], ys[0]), err(y[1], ys[1]))
+    assert err(xa.grad, xs.grad) < 1e-5
+    if mem is not None:
+        assert err(ma.grad, ms.grad) < 1e-5
+    names = ["ln_w", "ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo"]
+    for tag, q, r in (("a", qa, ra), ("b", qb, rb)):
+        for n, u, v in zip(names, q, r):
+            if n == "bk":
+                assert float(u.grad.abs().max()) == 0.0 and float(v.grad.abs().max()) == 0.0
+            else:
+                assert err(u.grad, v.grad) < 1e-4, (tag, n, err(u.grad, v.grad))
+
+
+@pytest.mark.parametrize("B,L,dq,D,H", [(3, 30, 300, 1024, 4), (4, 6, 40, 64, 4)])
+def test_pair_self_attention_equals_two_single_calls(B, L, dq, D, H):
+    """PairSelfAttnFn on two parameter sets == MHAFn (self attention, pre-norm, residual) called once per set"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd.functional import MHAFn, PairSelfAttnFn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + L)
+    rnd = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(dev)
+    def pset():
+        return [1 + 0.1 * rnd(dq), 0.1 * rnd(dq), rnd(D, dq, sc=dq ** -0.5), 0.1 * rnd(D), rnd(D, dq, sc=dq ** -0.5), 0.1 * rnd(D),
+                rnd(D, dq, sc=dq ** -0.5), 0.1 * rnd(D), rnd(dq, D, sc=D ** -0.5), 0.1 * rnd(dq)]
+    pa, pb = pset(), pset()
+    x2 = rnd(2, B, L, dq)
+    mask = torch.tril(torch.ones(L, L, dtype=torch.bool, device=dev)).repeat(B, 1, 1)
+    mask[0, :, L - 2:] = False
+    w2 = rnd(2, B, L, dq)
+    leaf = lambda ts: [t.clone().requires_grad_(True) for t in ts]
+    xa, qa, qb = x2.clone().requires_grad_(True), leaf(pa), leaf(pb)
+    y = PairSelfAttnFn.apply(xa, torch.cat([mask, mask]), H, 0.0, *qa, *qb)
+    (y * w2).sum().backward()
+    xs, ra, rb = x2.clone().requires_grad_(True), leaf(pa), leaf(pb)
+    ys = torch.stack([MHAFn.apply(xs[i], None, *r, mask, H, 0.0, True, None) for i, r in enumerate((ra, rb))])
+    (ys * w2).sum().backward()
+    err = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-20))
+    assert err(y, ys) < 1e-6
+    assert err(xa.grad, xs.grad) < 1e-5
+    names = ["ln_w", "ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo"]
+    for tag, q, r in (("a", qa, ra), ("b", qb, rb)):
+        for n, u, v in zip(names, q, r):
+            if n == "bk":        # exactly zero in exact arithmetic (a shift of every key's score): both are rounding residue
+                assert float(u.grad.norm()) < 0.05 * float(q[3].grad.norm()) and float(v.grad.norm()) < 0.05 * float(r[3].grad.norm())
+                continue
+            tol = 5e-3 if n in ("bq", "bv") else 1e-4                # bias sums are taken after the bf16 rounding of dQ|dK|dV here
+            assert err(u.grad, v.grad) < tol, (tag, n, err(u.grad, v.grad))
