@@ -874,7 +874,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
                          d->dropout_p == 0.f && !d->accumulate && !d->colsum;
   static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
   static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
-  bool big = force_tile ? force_tile == 2 : big_tiles >= big_min;
+  bool big = force_tile ? force_tile >= 2 : big_tiles >= big_min;
   // (128x128 tiles + K split for small outputs: re-measured slower than 64x64 tiles + K split since the deep-prefetch /
   //  epilogue changes -- V dW 30 vs 23 us, A-out dW 25 vs 18 us; kept behind BMHRL_GEMM_BIGSPLIT=1 as a tuning aid)
   static const int big_split = getenv("BMHRL_GEMM_BIGSPLIT") ? atoi(getenv("BMHRL_GEMM_BIGSPLIT")) : 0;
@@ -894,7 +894,15 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   }
   hipError_t e;
   // 128x128 tiles only when they still give every CU (256) a block; otherwise 64x64 tiles fill the chip better.
-  if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
+  // 128 x 64 tiles when 128 x 128 ones would give a CU at most one workgroup (the 4096 x 1024 projections of the video stream:
+  // 256 tiles): two workgroups per CU cover each other's waits -- 4096 x 1024 x 1024 19.3 -> 17.0 us, its dX 16.1 -> 13.7 us;
+  // with more columns (2048, 3072) the square tile's lower traffic per FLOP wins (26.5 vs 31.5 us).  Alone, that is: inside
+  // the captured step, where the audio branch runs next to these GEMMs, the step measured 6.06 - 6.23 ms with them against
+  // 5.95 ms without, so the option is off by default (BMHRL_GEMM_MIDMAX=256 turns it on, BMHRL_GEMM_TILE=3 forces it).
+  static const int mid_max = getenv("BMHRL_GEMM_MIDMAX") ? atoi(getenv("BMHRL_GEMM_MIDMAX")) : 0;
+  const bool mid = force_tile ? force_tile == 3 : (big && splits == 1 && big_tiles <= mid_max);
+  if (mid) e = launch<2, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
+  else if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   return hip_status(e);
 }
