@@ -568,8 +568,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // Adam over the flat bucket, parameter by parameter, writing each updated weight's bf16 shadow (or fp32 copy: concatenated
 // biases) in the same pass: the per-step shadow refresh (cast_segments over every weight: 221 MB read again) disappears.
-// seg = 6 int64 per parameter: offset in the flat bucket (elements), shadow address (0: none), rows, cols, shadow leading
-// dimension (elements; <= 0: the shadow is fp32, tightly packed), first block.  Block = 4096 consecutive elements.
+// seg = 7 int64 per parameter: offset in the flat bucket (elements), shadow address (0: none), rows, cols, shadow leading
+// dimension (elements; <= 0: the shadow is fp32, tightly packed), first block, gradient address (0: the flat gradient bucket
+// at the parameter's offset; else the parameter's fp32 gradient where autograd left it -- no gather copy).
+// Block = 4096 consecutive elements.
+constexpr int ADAM_WORDS = 7;
 __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg, float* __restrict__ p, const float* __restrict__ g,
                                      float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps,
                                      float wd, float bc1, float bc2_sqrt, float gscale, const int32_t* __restrict__ step_dev) {
@@ -581,10 +584,11 @@ __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg,
   int lo = 0, hi = n_seg - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (seg[mid * SEG_WORDS + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (seg[mid * ADAM_WORDS + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const int64_t* e = seg + lo * SEG_WORDS;
+  const int64_t* e = seg + lo * ADAM_WORDS;
   const long off = e[0], rows = e[2], cols = e[3], ldd = e[4];
+  g = e[6] ? reinterpret_cast<const float*>(e[6]) - off : g;        // (indexed with off + i below)
   const long total = rows * cols;
   const long base = ((long)blockIdx.x - e[5]) * SEG_ELEMS_PER_BLOCK;
   const long end = base + SEG_ELEMS_PER_BLOCK < total ? base + SEG_ELEMS_PER_BLOCK : total;
@@ -611,7 +615,7 @@ __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg,
     return;
   }
   bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(e[1]);
-  if ((cols & 3) == 0 && (ldd & 3) == 0 && (off & 3) == 0 && (e[1] & 7) == 0) {     // 16-byte accesses of the four arrays
+  if ((cols & 3) == 0 && (ldd & 3) == 0 && (off & 3) == 0 && (e[1] & 7) == 0 && (e[6] & 15) == 0) {     // 16-byte accesses of the four arrays
     for (long i = base + 4 * threadIdx.x; i < end; i += 4 * blockDim.x) {
       f32x4 gv = *reinterpret_cast<const f32x4*>(g + off + i);
       const f32x4 pv = *reinterpret_cast<const f32x4*>(p + off + i);

@@ -89,21 +89,23 @@ class ShadowCache:
         current, so the lookups of the following forward / backward are hits.  (The optimizer keeps the shadows of the
         parameters it owns current itself -- bmhrl_adam_segments writes them in the Adam pass -- so in a training step this
         usually finds nothing to do.)  Segment tables are cached per set of stale entries."""
-        live = [(k, e, 1) for k, e in self.w.items() if all(r() is not None for r in e[2])] + \
-               [(k, e, 0) for k, e in self.b.items() if all(r() is not None for r in e[2])]
-        live = [(k, e, kind) for k, e, kind in live if e[1].is_cuda and not self._is_current(e)]
+        live = []
+        for kind, store in ((1, self.w), (0, self.b)):
+            for k, e in store.items():
+                params = tuple(r() for r in e[2])          # strong references from here on (a collection may run any time)
+                if all(p is not None for p in params) and e[1].is_cuda and e[0] != self._version(params):
+                    live.append((k, e, kind, params))
         if not live:
             return
-        sig = tuple((k, kind, e[1].data_ptr()) + tuple(r().data_ptr() for r in e[2]) for k, e, kind in live)
+        sig = tuple((k, kind, e[1].data_ptr()) + tuple(p.data_ptr() for p in params) for k, e, kind, params in live)
         plans = self.__dict__.setdefault("_plans", {})
         if sig not in plans:
             if len(plans) > 16:
                 plans.clear()
             rows_, blk = [], 0
-            for k, e, kind in live:
+            for k, e, kind, params in live:
                 buf, off = e[1], 0
-                for r in e[2]:
-                    p = r()
+                for p in params:
                     if kind:      # weight: (N_p, K) fp32 -> rows [off, off + N_p) of the (N, ld) bf16 shadow
                         n, kk, ld = p.shape[0], p.shape[1], buf.shape[1]
                         rows_.append([p.data_ptr(), buf.data_ptr() + 2 * off * ld, n, kk, ld, blk])
@@ -118,8 +120,7 @@ class ShadowCache:
             plans[sig] = (torch.tensor(rows_, dtype=torch.int64).to(dev), len(rows_), blk)
         table, n_seg, n_blk = plans[sig]
         ops.cast_segments(table, n_seg, n_blk)
-        for k, e, kind in live:
-            params = tuple(r() for r in e[2])
+        for k, e, kind, params in live:
             (self.w if kind else self.b)[k] = (self._version(params), e[1], e[2])
 
 

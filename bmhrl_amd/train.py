@@ -54,6 +54,8 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
 
+    direct_grads = os.environ.get("BMHRL_DIRECT_GRADS", "1") == "1"   # one rank: Adam reads the gradients in place (no gather)
+
     fused_shadows = os.environ.get("BMHRL_FUSED_SHADOWS", "1") == "1"   # False: plain Adam kernel + a whole-cache shadow refresh at the start of the next step
 
     def mark_uncovered_stale(self):
@@ -81,8 +83,9 @@ class FlatAdam:
                 if any(mine):
                     groups.append((kind, key, e[1], params, mine))
         sig = tuple((kind, key, buf.data_ptr()) for kind, key, buf, _, _ in groups)
+        gptrs = self.__dict__.get("_direct_ptrs")
         cached = self.__dict__.get("_seg_plan")
-        if cached is not None and cached[0] == sig:
+        if cached is not None and cached[0] == sig and cached[2] == gptrs:
             return cached[1]
         if torch.cuda.is_current_stream_capturing():
             return None
@@ -106,12 +109,15 @@ class FlatAdam:
                         dst[id(p)] = (buf.data_ptr() + 4 * off, 1, p.numel(), 0)
                     off += p.numel()
         rows, blk = [], 0
-        for p, o, sz in zip(self.params, self.offsets, self.sizes):
+        if gptrs is not None and self.__dict__.get("_grad_dirty", True):
+            self.grad.zero_()              # parameters without a gradient read zeros from the bucket (nothing else writes it now)
+            self._grad_dirty = False
+        for i, (p, o, sz) in enumerate(zip(self.params, self.offsets, self.sizes)):
             d = dst.get(id(p), (0, 1, sz, 0))
-            rows.append([o, d[0], d[1], d[2], d[3], blk])
+            rows.append([o, d[0], d[1], d[2], d[3], blk, gptrs[i] if gptrs is not None else 0])
             blk += (sz + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
         plan = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), blk, uncovered)
-        self._seg_plan = (sig, plan)
+        self._seg_plan = (sig, plan, gptrs)
         return plan
 
     def set_buckets(self, counts: List[int]):
@@ -140,6 +146,17 @@ class FlatAdam:
         segmented copy kernel (bmhrl_cast_segments, fp32 mode): inside a trainer step the gradients live at fixed
         addresses (slices of the step scratch arena), so the segment table is built once and reused.
         part: None = all parameters, i = bucket i of set_buckets() / set_split()."""
+        self._direct_ptrs = None
+        if part is None and self.direct_grads and self.fused_shadows and self.flat.is_cuda and \
+                not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            # one process: nothing needs the gradients side by side -- the Adam pass reads each one where autograd left it
+            ptrs = tuple(0 if p.grad is None else
+                         (p.grad.data_ptr() if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else -1)
+                         for p in self.params)
+            if -1 not in ptrs and (not torch.cuda.is_current_stream_capturing() or
+                                   self.__dict__.get("_seg_plan", (None, None, None))[2:] == (ptrs,)):
+                self._direct_ptrs = ptrs
+                return
         dst, src, missing = [], [], []
         lo, hi = self._bucket_range(part)
         for p, gv in zip(self.params[lo:hi], self.grad_views[lo:hi]):
@@ -148,6 +165,7 @@ class FlatAdam:
             else:
                 dst.append(gv)
                 src.append(p.grad)
+        self._grad_dirty = True
         if missing:
             torch._foreach_zero_(missing)
         if not dst:

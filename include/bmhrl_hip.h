@@ -299,8 +299,9 @@ int bmhrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float grad_scale, bmhrl_stream_t stream);
 
 /* The same update driven by a per-parameter table, writing each updated weight's bf16 shadow (or fp32 copy) in the same
- * pass.  segments: int64 (n_segments, 6) on the device = {offset of the parameter in the flat bucket (elements), shadow
- * address (0: none), rows, cols, shadow leading dimension in elements (<= 0: fp32 copy, tightly packed), first block};
+ * pass.  segments: int64 (n_segments, 7) on the device = {offset of the parameter in the flat bucket (elements), shadow
+ * address (0: none), rows, cols, shadow leading dimension in elements (<= 0: fp32 copy, tightly packed), first block,
+ * address of the parameter's fp32 gradient (0: grad + offset, the flat bucket)};
  * a block owns 4096 consecutive elements of one parameter, n_blocks = sum over parameters of ceil(rows * cols / 4096). */
 int bmhrl_adam_segments(const int64_t* segments, int32_t n_segments, int32_t n_blocks, float* param, const float* grad,
                         float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
