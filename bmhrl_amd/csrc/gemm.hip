@@ -74,12 +74,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
         sCb[row * SCB + col] = (bf16_t)v;
       }
     };
-    stage_bf16(acc[0][0], 0, 0);
-    if constexpr (TN > 1) stage_bf16(acc[0][1], 0, 1);
-    if constexpr (TM > 1) {
-      stage_bf16(acc[1][0], 1, 0);
-      if constexpr (TN > 1) stage_bf16(acc[1][1], 1, 1);
-    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) stage_bf16(acc[mi][ni], mi, ni);
     __syncthreads();
     constexpr int G8 = BM * BN / 8 / 256;          // 16-byte groups per thread
 #pragma unroll
@@ -162,11 +160,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
         r1[g] = *reinterpret_cast<const f32x4*>(sRV + row0 + 8 * g);
         r2[g] = *reinterpret_cast<const f32x4*>(sRV2 + row0 + 8 * g);
       }
-      finish(acc[mi][0], mi, 0, r1, r2);
-      if constexpr (TN > 1) finish(acc[mi][1], mi, 1, r1, r2);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) finish(acc[mi][ni], mi, ni, r1, r2);
     };
-    finish_rows(0);
-    if constexpr (TM > 1) finish_rows(1);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) finish_rows(mi);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < G8; ++i) {
@@ -190,12 +188,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
     for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * SC] = av[r];
   };
-  stage(acc[0][0], 0, 0);
-  if constexpr (TN > 1) stage(acc[0][1], 0, 1);
-  if constexpr (TM > 1) {
-    stage(acc[1][0], 1, 0);
-    if constexpr (TN > 1) stage(acc[1][1], 1, 1);
-  }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) stage(acc[mi][ni], mi, ni);
   __syncthreads();
 
   float* __restrict__ Cg = p.C ? p.C + b1 * p.c_sb1 + b2 * p.c_sb2 : nullptr;
@@ -894,6 +890,9 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   }
   hipError_t e;
   // 128x128 tiles only when they still give every CU (256) a block; otherwise 64x64 tiles fill the chip better.
+  // (256 x 128 tiles, one workgroup of 4 waves x 128 x 64 per CU with 512 registers per wave -- 48 KiB of operands per k-step for
+  // twice the FLOPs of a square tile -- were built and measured SLOWER on every shape: 4096 x 3072 x 1024 48.5 vs 38.5 us,
+  // 8192^3 1025 vs 1097 TF/s: what two co-resident workgroups hide for each other outweighs the lower traffic per FLOP.)
   // 128 x 64 tiles when 128 x 128 ones would give a CU at most one workgroup (the 4096 x 1024 projections of the video stream:
   // 256 tiles): two workgroups per CU cover each other's waits -- 4096 x 1024 x 1024 19.3 -> 17.0 us, its dX 16.1 -> 13.7 us;
   // with more columns (2048, 3072) the square tile's lower traffic per FLOP wins (26.5 vs 31.5 us).  Alone, that is: inside
