@@ -262,7 +262,7 @@ class SegmentCritic(nn.Module):
             return self.lin(self.relu2(h))
 
     wavefront = True       # False: one GEMM + L step launches per layer (the first native form; kept for A/B and tests)
-    wave_chunk = 3         # time steps a layer trails the one below: W_ih is read once per chunk (ops.rnn_wavefront)
+    wave_chunk = int(os.environ.get("BMHRL_WAVE_CHUNK", "3"))         # time steps a layer trails the one below: W_ih is read once per chunk (ops.rnn_wavefront)
 
     def score_and_labels(self, emb, threshold):
         """HIP path, fp32.  Returns (score (B, L, 1), labels (B, L) int32 = sigmoid(score) > threshold).
