@@ -136,6 +136,26 @@ def attention_roofline(dev, B, H, Tv, Ta, iters=50):
     visited2 = sum(min(Sk2, -(-int(v_mask[b].sum()) // 32) * 32) for b in range(B))
     issued_av = 4.0 * Sq2 * visited2 * D
 
+    # ---- the same two launches at the long-segment shapes of BASELINE configs[4] (B=8, Tv=1024, Ta=2048, unmasked): where
+    # the fixed cost of a launch is amortised.  Secondary figures: the headline stays the step's own shape.
+    def long_shapes():
+        Bl, Tvl, Tal = 8, 1024, 2048
+        Ql = (0.5 * torch.randn(Bl, Tvl, H, dm, generator=g)).to(dev).to(torch.bfloat16)
+        Xl = torch.randn(Bl, Tal, dm, generator=g).to(dev).to(torch.bfloat16)
+        cl = torch.empty(Bl, Tvl, H, dm, dtype=torch.bfloat16, device=dev)
+        m1, s1 = torch.empty(Bl, H, Tvl, device=dev), torch.empty(Bl, H, Tvl, device=dev)
+        t_va = _time_launches(lambda: ops.attention_shared128_fwd(Ql, Xl, cl, m1, s1, None, 0, Bl, H, Tvl, Tal, scale, H * dm, dm,
+                                                                  H * dm), 20)
+        Q3, K3, V3 = (torch.randn(Bl, S, D, generator=g).to(dev).to(torch.bfloat16) for S in (Tal, Tvl, Tvl))
+        O3 = torch.empty(Bl, Tal, D, dtype=torch.bfloat16, device=dev)
+        m3, s3 = torch.empty(Bl, H, Tal, device=dev), torch.empty(Bl, H, Tal, device=dev)
+        t_av = _time_launches(lambda: ops.attention_fwd(Q3, K3, V3, O3, m3, s3, None, 0, 0, Bl, H, Tal, Tvl, dk, scale, D, D, D, D), 20)
+        f_va, f_av = 4.0 * Bl * H * Tvl * Tal * dm, 4.0 * Bl * Tal * Tvl * D
+        return {"shape": {"B": Bl, "Tv": Tvl, "Ta": Tal, "mask": "none"},
+                "V<-A": {"launch_us": t_va * 1e6, "flops_per_launch": f_va, "frac": f_va / t_va / 2.5e15},
+                "A<-V": {"launch_us": t_av * 1e6, "flops_per_launch": f_av, "frac": f_av / t_av / 2.5e15}}
+    long_seq = long_shapes()
+
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
     tj = os.path.join(ROOT, "profiles", "r02_attn_traffic.json")
     if os.path.exists(tj):
@@ -159,6 +179,7 @@ def attention_roofline(dev, B, H, Tv, Ta, iters=50):
                                          "removes the 2*B*Sk*128*2048-flop K|V projection of the audio rows and its backward)",
                                  "us": sec_call * 1e6, "flops": call_va, "achieved": tf(call_va, sec_call),
                                  "frac": tf(call_va, sec_call) / 2500.0},
+        "config5_shapes": long_seq,
     }
 
 
