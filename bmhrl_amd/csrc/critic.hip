@@ -146,7 +146,12 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   const bmhrl_rnn_layer& P = tab.l[layer];
   const int GATES = P.gates;
   const int tid = threadIdx.x;
-  const int u0 = blockIdx.x * UBW, b0 = blockIdx.y * 16;
+  // blockIdx.y = role * (batch blocks) + batch block.  Role 0 runs the cell (and, on the first step of a chunk, the input
+  // projection of that step); roles 1 .. T-1 exist on chunk steps only and project step t + role of the chunk into P.xproj:
+  // the T projections of a chunk run side by side instead of one after the other inside the cell's block.
+  const int nb16 = (B + 15) / 16;
+  const int role = (int)blockIdx.y / nb16;
+  const int u0 = blockIdx.x * UBW, b0 = ((int)blockIdx.y - role * nb16) * 16;
   const int sg = tid >> 4, bl = tid & 15;
   bool row_ok[SPT];
   long wrow[SPT];
@@ -226,37 +231,49 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
     bias_x[q] = row_ok[q] ? P.b_ih[wrow[q]] + (GATES == 4 ? P.b_hh[wrow[q]] : 0.f) : 0.f;
     xp[q] = 0.f;
   }
+  if (role > 0) {                                       // projection of step t + role of the chunk that starts at t
+    if (T == 1 || t % T != 0 || t + role >= L) return;  // (uniform for the block)
+    f32x4 wv[SPT][NP];
+    load_rows(P.w_ih, K, wv);
+    stage(P.in_seq + (long)(t + role) * P.in_ld, (long)L * P.in_ld, K, true);
+    __syncthreads();
+    float v[SPT];
+    apply_rows(wv, K, v);
+#pragma unroll
+    for (int q = 0; q < SPT; ++q)
+      if (row_ok[q] && b_ok) P.xproj[((long)(b0 + bl) * L + t + role) * (GATES * H) + wrow[q]] = v[q] + bias_x[q];
+    return;
+  }
   if (T == 1 || t % T == 0) {
     f32x4 wv[SPT][NP];
     load_rows(P.w_ih, K, wv);
-    const int nt = T == 1 ? 1 : min(T, L - t);
-    for (int tt = 0; tt < nt; ++tt) {
-      stage(P.in_seq + (long)(t + tt) * P.in_ld, (long)L * P.in_ld, K, true);
-      __syncthreads();
-      float v[SPT];
-      apply_rows(wv, K, v);                             // (every lane takes part in the shuffles)
+    stage(P.in_seq + (long)t * P.in_ld, (long)L * P.in_ld, K, true);
+    __syncthreads();
+    float v[SPT];
+    apply_rows(wv, K, v);                               // (every lane takes part in the shuffles)
 #pragma unroll
-      for (int q = 0; q < SPT; ++q) {
-        if (tt == 0) xp[q] = v[q] + bias_x[q];
-        else if (row_ok[q] && b_ok) P.xproj[((long)(b0 + bl) * L + t + tt) * (GATES * H) + wrow[q]] = v[q] + bias_x[q];
-      }
-      __syncthreads();
-    }
+    for (int q = 0; q < SPT; ++q) xp[q] = v[q] + bias_x[q];
+    __syncthreads();
   } else if (b_ok) {
 #pragma unroll
     for (int q = 0; q < SPT; ++q)                       // stored by this thread at the chunk's first step
       if (row_ok[q]) xp[q] = P.xproj[((long)(b0 + bl) * L + t) * (GATES * H) + wrow[q]];
   }
-  // pass 2: h_{t-1}
-  stage(P.h[(t + 1) & 1], H, H, t > 0);
-  __syncthreads();
+  // pass 2: h_{t-1}.  The recurrent weight rows are requested BEFORE h is staged: they depend on nothing, and their
+  // latency (they come from the Infinity Cache: the six layers' 31.7 MB do not stay in an XCD's L2 between launches) then
+  // passes under the h load -> LDS -> barrier chain instead of following it.
   float acc[SPT];
 #pragma unroll
   for (int q = 0; q < SPT; ++q) acc[q] = 0.f;
   if (t > 0) {                                         // t is uniform
     f32x4 wv[SPT][NP];
     load_rows(P.w_hh, H, wv);
+    stage(P.h[(t + 1) & 1], H, H, true);
+    __syncthreads();
     apply_rows(wv, H, acc);
+  } else {
+    stage(P.h[(t + 1) & 1], H, H, false);
+    __syncthreads();
   }
 #pragma unroll
   for (int q = 0; q < SPT; ++q) {
@@ -351,8 +368,12 @@ extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_laye
   }
   static const int spt = getenv("BMHRL_RNN_SPT") ? atoi(getenv("BMHRL_RNN_SPT")) : 2;     // gate rows per thread (tuning aid: 1)
   const int ubw = UB * (spt == 1 ? 1 : 2);
-  dim3 grid((unsigned)((H + ubw - 1) / ubw), (unsigned)((B + 15) / 16), (unsigned)n_layers), block(256);
+  const unsigned nb16 = (unsigned)((B + 15) / 16);
   for (int s = 0; s < L + chunk * (n_layers - 1); ++s) {
+    // launches in which the layers start a chunk (every layer trails the one below by `chunk` steps, so they all do in the
+    // same launches) carry the extra projection roles
+    const unsigned roles = (chunk > 1 && s % chunk == 0) ? (unsigned)chunk : 1u;
+    dim3 grid((unsigned)((H + ubw - 1) / ubw), nb16 * roles, (unsigned)n_layers), block(256);
     if (spt == 1) hipLaunchKernelGGL(rnn_wave_kernel<1>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
     else hipLaunchKernelGGL(rnn_wave_kernel<2>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
   }
