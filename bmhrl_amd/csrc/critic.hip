@@ -372,7 +372,7 @@ extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_laye
   for (int s = 0; s < L + chunk * (n_layers - 1); ++s) {
     // launches in which the layers start a chunk (every layer trails the one below by `chunk` steps, so they all do in the
     // same launches) carry the extra projection roles
-    const unsigned roles = (chunk > 1 && s % chunk == 0) ? (unsigned)chunk : 1u;
+    const unsigned roles = (unsigned)chunk;            // (the same grid in every launch; the extra roles of a non-chunk launch exit at once)
     dim3 grid((unsigned)((H + ubw - 1) / ubw), nb16 * roles, (unsigned)n_layers), block(256);
     if (spt == 1) hipLaunchKernelGGL(rnn_wave_kernel<1>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
     else hipLaunchKernelGGL(rnn_wave_kernel<2>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
