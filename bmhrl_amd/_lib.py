@@ -84,6 +84,7 @@ PROTOTYPES = {
     "bmhrl_rnn_wavefront": [ptr, i32, i32, i32, i32, i32, ptr],
     "bmhrl_critic_head": [ptr, ptr, ptr, f32, ptr, ptr, i64, i32, ptr],
     "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
+    "bmhrl_make_masks": [ptr, i64, ptr, i64, ptr, i32, i32, i32, i32, i64, i32, ptr, ptr, ptr, ptr],
     "bmhrl_adam_segments": [ptr, i32, i32, ptr, ptr, ptr, ptr, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
 }
 

@@ -644,6 +644,30 @@ __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg,
   }
 }
 
+// All masks of a step in one launch (model/masking.py:18-55 for the bimodal case): V_mask[b][t] = rgb[b][t][0] != 0,
+// A_mask[b][t] = audio[b][t][0] != 0, C_mask[b][i][j] = (trg[b][j] != pad) && j <= i; each written `copies` times back to
+// back (the paired fusion stacks address them as 2 B samples).
+__global__ void make_masks_kernel(const float* __restrict__ rgb, long ld_rgb, const float* __restrict__ audio, long ld_aud,
+                                  const int64_t* __restrict__ trg, int B, int Tv, int Ta, int L, int64_t pad, int copies,
+                                  uint8_t* __restrict__ vm, uint8_t* __restrict__ am, uint8_t* __restrict__ cm) {
+  const long nv = (long)B * Tv, na = (long)B * Ta, nc = (long)B * L * L;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv + na + nc; i += (long)gridDim.x * blockDim.x) {
+    uint8_t v;
+    uint8_t* dst;
+    long n, j;
+    if (i < nv) { j = i; v = rgb[j * ld_rgb] != 0.f; dst = vm; n = nv; }
+    else if (i < nv + na) { j = i - nv; v = audio[j * ld_aud] != 0.f; dst = am; n = na; }
+    else {
+      j = i - nv - na;
+      const long b = j / ((long)L * L), r = j - b * L * L;
+      const int qi = (int)(r / L), kj = (int)(r - (long)qi * L);
+      v = (trg[b * L + kj] != pad) && kj <= qi;
+      dst = cm; n = nc;
+    }
+    for (int c = 0; c < copies; ++c) dst[c * n + j] = v;
+  }
+}
+
 inline unsigned grid_for(long total, int block = 256, int cap = 2048) {
   long g = (total + block - 1) / block;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -926,8 +950,18 @@ extern "C" int bmhrl_adam_segments(const int64_t* segments, int32_t n_segments, 
   return hip_status(hipGetLastError());
 }
 
+extern "C" int bmhrl_make_masks(const float* rgb, int64_t ld_rgb, const float* audio, int64_t ld_aud, const int64_t* trg, int32_t B,
+                                int32_t Tv, int32_t Ta, int32_t L, int64_t pad_idx, int32_t copies, uint8_t* v_mask,
+                                uint8_t* a_mask, uint8_t* c_mask, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(rgb && audio && trg && v_mask && a_mask && c_mask && B > 0 && Tv > 0 && Ta > 0 && L > 0 && copies >= 1);
+  const long total = (long)B * (Tv + Ta + (long)L * L);
+  hipLaunchKernelGGL(make_masks_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), rgb, (long)ld_rgb, audio, (long)ld_aud, trg,
+                     B, Tv, Ta, L, pad_idx, copies, v_mask, a_mask, c_mask);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 2: bmhrl_gemm_desc.colsum, bmhrl_cast_colsum_bf16, bmhrl_cast_segments
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
-// 7: bmhrl_adam_segments   8: bmhrl_gemm_desc.colsum_sb1 / bias_sb1, fp16 attention entry points
-extern "C" int bmhrl_hip_abi_version(void) { return 8; }
+// 7: bmhrl_adam_segments   8: bmhrl_gemm_desc.colsum_sb1 / bias_sb1, fp16 attention entry points   9: bmhrl_make_masks
+extern "C" int bmhrl_hip_abi_version(void) { return 9; }

@@ -193,7 +193,10 @@ def fusion_pair(fw, fm, C, Av, Va, masks):
     stack; returns (worker features, manager features)."""
     from ..functional import PairGateFn, PairMemAttnFn, PairRowFn, PairSelfAttnFn
     C2 = torch.stack([C, C])                                     # (2, B, L, d_caps): stack 0 = worker, 1 = manager
-    cm2, am2, vm2 = (torch.cat([masks[k], masks[k]]) for k in ('C_mask', 'A_mask', 'V_mask'))
+    if '_pair' in masks:                                         # (the trainer builds the doubled masks with the single ones)
+        cm2, am2, vm2 = masks['_pair']
+    else:
+        cm2, am2, vm2 = (torch.cat([masks[k], masks[k]]) for k in ('C_mask', 'A_mask', 'V_mask'))
     for lw, lm in zip(fw.decoder.layers, fm.decoder.layers):
         H = lw.self_att.H
         p = lw.self_att.dout_p if lw.training else 0.0

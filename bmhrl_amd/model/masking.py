@@ -9,10 +9,26 @@ def subsequent_mask(size, device=None):
     return torch.tril(torch.ones(1, size, size, dtype=torch.uint8, device=device), 0)
 
 
+_TRIL = {}
+
+
+def _tril_bool(size, device):
+    """the same triangle as a cached bool constant per (size, device): three launches less per step"""
+    key = (size, str(device))
+    t = _TRIL.get(key)
+    if t is None:
+        t = subsequent_mask(size, device).bool()
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):     # (a graph's private pool must not leak out)
+            if len(_TRIL) > 64:
+                _TRIL.clear()
+            _TRIL[key] = t
+    return t
+
+
 def c_mask(trg, pad_idx):
     """key-padding & causal mask of a caption batch, (B, L, L).  reference :13-15"""
     pad = (trg != pad_idx).unsqueeze(-2)
-    return pad & subsequent_mask(trg.size(-1), trg.device).type_as(pad)
+    return pad & _tril_bool(trg.size(-1), trg.device)
 
 
 def mask(src, trg, pad_idx, data_pad=0):

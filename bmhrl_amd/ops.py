@@ -305,3 +305,21 @@ def adam_segments(table, n_segments, n_blocks, param, grad, exp_avg, exp_avg_sq,
     _lib.check(_lib.load().bmhrl_adam_segments(table.data_ptr(), n_segments, n_blocks, param.data_ptr(), grad.data_ptr(),
                                                exp_avg.data_ptr(), exp_avg_sq.data_ptr(), lr, beta1, beta2, eps, weight_decay,
                                                step, _p(step_dev), grad_scale, stream()), "bmhrl_adam_segments")
+
+
+def make_masks(rgb, audio, trg, pad_idx, copies=1):
+    """V_mask (copies*B, 1, Tv), A_mask (copies*B, 1, Ta), C_mask (copies*B, L, L) as bool tensors, one launch
+    (model/masking.py:18-55, bimodal case; copies > 1: the same masks laid out that many times)"""
+    _need_cuda(rgb, audio, trg)
+    B, Tv = rgb.shape[:2]
+    Ta, L = audio.shape[1], trg.shape[1]
+    if rgb.stride(2) != 1 or rgb.stride(0) != Tv * rgb.stride(1) or audio.stride(2) != 1 or audio.stride(0) != Ta * audio.stride(1):
+        raise RuntimeError("make_masks: feature stacks must be (B, T, D) with contiguous rows")
+    trg = trg.contiguous()
+    vm = torch.empty(copies * B, 1, Tv, dtype=torch.bool, device=rgb.device)
+    am = torch.empty(copies * B, 1, Ta, dtype=torch.bool, device=rgb.device)
+    cm = torch.empty(copies * B, L, L, dtype=torch.bool, device=rgb.device)
+    _lib.check(_lib.load().bmhrl_make_masks(rgb.data_ptr(), rgb.stride(1), audio.data_ptr(), audio.stride(1), trg.data_ptr(), B, Tv,
+                                            Ta, L, pad_idx, copies, vm.data_ptr(), am.data_ptr(), cm.data_ptr(), stream()),
+               "bmhrl_make_masks")
+    return vm, am, cm

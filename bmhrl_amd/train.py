@@ -333,7 +333,13 @@ class CaptionTrainer:
 
     # ------------------------------------------------------------------ one step, eager
     def _forward_loss(self, fs, trg_in, trg_y, rl=None):
-        masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
+        if fs["rgb"].is_cuda:
+            # every mask of the step, and their doubled copies for the paired fusion stacks, in one launch
+            B = trg_in.shape[0]
+            vm2, am2, cm2 = ops.make_masks(fs["rgb"], fs["audio"], trg_in, self.pad_idx, copies=2)
+            masks = {"V_mask": vm2[:B], "A_mask": am2[:B], "C_mask": cm2[:B], "_pair": (cm2, am2, vm2)}
+        else:
+            masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
         pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
         loss_mask = trg_y != self.pad_idx
         n_tokens = loss_mask.sum()

@@ -307,6 +307,13 @@ int bmhrl_adam_segments(const int64_t* segments, int32_t n_segments, int32_t n_b
                         float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int32_t step, const int32_t* step_dev, float grad_scale, bmhrl_stream_t stream);
 
+/* The masks of a bimodal step in one launch (model/masking.py:18-55): v_mask[b][t] = rgb[b][t][0] != 0 (row stride ld_rgb
+ * elements), a_mask likewise from audio, c_mask[b][i][j] = trg[b][j] != pad_idx && j <= i; bytes 0 / 1, each mask written
+ * `copies` times back to back ((copies, B, .) layout). */
+int bmhrl_make_masks(const float* rgb, int64_t ld_rgb, const float* audio, int64_t ld_aud, const int64_t* trg, int32_t B,
+                     int32_t Tv, int32_t Ta, int32_t L, int64_t pad_idx, int32_t copies, uint8_t* v_mask, uint8_t* a_mask,
+                     uint8_t* c_mask, bmhrl_stream_t stream);
+
 /* Library self-description: returns the gfx target the kernels were built for ("gfx950"). */
 const char* bmhrl_hip_arch(void);
 int bmhrl_hip_abi_version(void);

@@ -494,3 +494,21 @@ def test_adam_matches_torch(dev):
         opt.step()
         ops.adam_step(p, grad, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
     assert rel_err(p, ref.data) < 1e-6
+
+
+def test_make_masks_kernel_equals_the_reference_functions(dev):
+    """bmhrl_make_masks == model/masking.py make_masks (V_mask from rgb column 0, A_mask from audio column 0, C_mask = key
+    padding & lower triangle), single and doubled"""
+    from bmhrl_amd import ops, synthetic as syn
+    from bmhrl_amd.model.masking import make_masks
+    b = syn.synthetic_batch(5, 37, 90, 11, 60, seed=3, min_len=3)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    fs["rgb"][2, 5, 0] = 0.0                       # a zero first feature inside the clip masks that frame too
+    trg = b["captions"][:, :-1].to(dev)
+    ref = make_masks(fs, trg, "audio_video", 1)
+    for copies in (1, 2):
+        vm, am, cm = ops.make_masks(fs["rgb"], fs["audio"], trg, 1, copies=copies)
+        for got, want in ((vm, ref["V_mask"]), (am, ref["A_mask"]), (cm, ref["C_mask"])):
+            assert got.dtype == torch.bool and got.shape[0] == copies * 5
+            assert torch.equal(got, torch.cat([want] * copies))
+    assert not bool(ref["V_mask"].all()) and not bool(ref["C_mask"][:, -1].all())      # padding is present in the case
