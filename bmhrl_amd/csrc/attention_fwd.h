@@ -925,6 +925,10 @@ int attention128_entry(const void* Qp, int64_t ldq, const void* X, int64_t ldx, 
   hipError_t e;
   if (code == 41) e = launch_attn<DK, 4, 1, 4, true, true>(a, stream);
   else if (code == 22) e = launch_attn<DK, 2, 2, 4, true, true>(a, stream);
+#ifdef BMHRL_ATTN_EXPERIMENTS
+  else if (code == 24) e = launch_attn<DK, 2, 4, 3, true, true>(a, stream);
+  else if (code == 14) e = launch_attn<DK, 1, 4, 3, true, true>(a, stream);
+#endif
   else return -22;
   attn_trace_dump("attn128", Sq, Sk, stream);
   return hip_status(e);
