@@ -37,12 +37,20 @@ class ShadowCache:
     def _alive(ent, params):
         return ent is not None and all(r() is p for r, p in zip(ent[2], params))
 
-    def _version(self, params):
-        return (self.epoch,) + tuple(p._version for p in params) + (params[0].device,)
+    def _version(self, params, kind=None, key=None):
+        """what a shadow of these parameters was made from.  autograd's version counters do not see the optimizer kernel
+        (it writes through raw pointers), so a parameter owned by a FlatAdam also contributes that optimizer's generation
+        -- it moves with every step / graph replay -- unless the optimizer's own pass maintains this very entry."""
+        gens = []
+        for p in params:
+            o = getattr(p, "_bmhrl_owner", None)
+            o = o() if o is not None else None
+            gens.append(0 if o is None else o.shadow_generation(kind, key))
+        return (self.epoch,) + tuple(p._version for p in params) + tuple(gens) + (params[0].device,)
 
     def weight(self, *params):
         key = tuple(id(p) for p in params)
-        ver = self._version(params)
+        ver = self._version(params, 1, key)
         ent = self.w.get(key)
         if not self._alive(ent, params):   # id() of a freed parameter can be reused by a new one
             ent = None
@@ -63,7 +71,7 @@ class ShadowCache:
         if len(params) == 1:
             return params[0].detach()
         key = tuple(id(p) for p in params)
-        ver = self._version(params)
+        ver = self._version(params, 0, key)
         ent = self.b.get(key)
         if self._alive(ent, params) and ent[0] == ver:
             return ent[1]
@@ -73,9 +81,9 @@ class ShadowCache:
 
 
     # ---- refresh of every stale entry in one launch
-    def _is_current(self, e):
+    def _is_current(self, kind, key, e):
         params = tuple(r() for r in e[2])
-        return all(p is not None for p in params) and e[0] == self._version(params)
+        return all(p is not None for p in params) and e[0] == self._version(params, kind, key)
 
     def mark_stale(self, kind, key):
         """the parameters of this entry were written behind autograd's back (optimizer kernel) without their shadow"""
@@ -93,7 +101,7 @@ class ShadowCache:
         for kind, store in ((1, self.w), (0, self.b)):
             for k, e in store.items():
                 params = tuple(r() for r in e[2])          # strong references from here on (a collection may run any time)
-                if all(p is not None for p in params) and e[1].is_cuda and e[0] != self._version(params):
+                if all(p is not None for p in params) and e[1].is_cuda and e[0] != self._version(params, kind, k):
                     live.append((k, e, kind, params))
         if not live:
             return
@@ -121,7 +129,7 @@ class ShadowCache:
         table, n_seg, n_blk = plans[sig]
         ops.cast_segments(table, n_seg, n_blk)
         for k, e, kind, params in live:
-            (self.w if kind else self.b)[k] = (self._version(params), e[1], e[2])
+            (self.w if kind else self.b)[k] = (self._version(params, kind, k), e[1], e[2])
 
 
 SHADOWS = ShadowCache()

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from types import SimpleNamespace
 import os
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -48,6 +49,14 @@ class FlatAdam:
         self.grad_views = [self.grad[o:o + s].view(p.shape) for p, o, s in zip(self.params, self.offsets, self.sizes)]
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
+        # shadows (bf16 copies of weights, functional.ShadowCache) of these parameters: `generation` moves with every update
+        # -- also with every replay of a captured step, which no host code sees -- and `maintained` names the shadow entries
+        # the Adam pass writes itself; every other entry that involves one of these parameters is stale after an update
+        self.generation = 0
+        self.maintained = set()
+        me = weakref.ref(self)
+        for p in self.params:
+            p._bmhrl_owner = me
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # advanced on the device (graph-safe)
 
     def zero_grad(self):
@@ -57,6 +66,9 @@ class FlatAdam:
     direct_grads = os.environ.get("BMHRL_DIRECT_GRADS", "1") == "1"   # one rank: Adam reads the gradients in place (no gather)
 
     fused_shadows = os.environ.get("BMHRL_FUSED_SHADOWS", "1") == "1"   # False: plain Adam kernel + a whole-cache shadow refresh at the start of the next step
+
+    def shadow_generation(self, kind, key):
+        return -1 if (kind, key) in self.maintained else self.generation
 
     def mark_uncovered_stale(self):
         """shadow groups this optimizer changes parameters of but cannot write (see _segment_plan) must be re-cast at the
@@ -118,6 +130,7 @@ class FlatAdam:
             blk += (sz + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
         plan = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), blk, uncovered)
         self._seg_plan = (sig, plan, gptrs)
+        self.maintained = {(kind, key) for kind, key, _, _, _ in groups if (kind, key) not in set(uncovered)}
         return plan
 
     def set_buckets(self, counts: List[int]):
@@ -204,6 +217,7 @@ class FlatAdam:
 
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
+        self.generation += 1
         b1, b2 = self.betas
         if self.flat.is_cuda:
             self.step_dev.add_(1)
@@ -523,6 +537,9 @@ class CaptionTrainer:
                 self.static[k].copy_(fs[k])
             self.static["captions"].copy_(captions)
         self._sync_token_weight(self.static["captions"])
+        for o in (self.opt, getattr(self, "vopt", None)):     # the captured Adam pass changes the weights behind the host's back
+            if o is not None:
+                o.generation += 1
         self.graph_a.replay()
         if self.graph_b is None:                  # single process: forward, backward and Adam are one graph
             return self.static_loss

@@ -193,7 +193,7 @@ def test_adam_pass_keeps_weight_shadows_current(setup):
                         params = [r() for r in refs]
                         if any(p is None or id(p) not in mine for p in params):
                             continue
-                        assert ver == SHADOWS._version(tuple(params))          # marked current ...
+                        assert SHADOWS._is_current(1 if is_w else 0, key, (ver, buf, refs))      # held current ...
                         off = 0
                         for p in params:                                       # ... and really is
                             if is_w:
@@ -207,3 +207,37 @@ def test_adam_pass_keeps_weight_shadows_current(setup):
         finally:
             FlatAdam.fused_shadows = True
     assert all(abs(a - c) <= 2e-3 * abs(c) for a, c in zip(losses[True], losses[False])), losses
+
+
+def test_shadows_made_after_capture_follow_the_replayed_updates(setup):
+    """A captured step updates the weights without any host code running, and autograd's version counters do not see the
+    optimizer kernel: shadow entries the captured Adam pass does not maintain itself (here: the per-module groups the decoders
+    use, created AFTER the capture) must still be re-made after replays -- FlatAdam.generation carries that."""
+    from bmhrl_amd.decode import greedy_decode
+    from bmhrl_amd.functional import SHADOWS
+    from bmhrl_amd.train import CaptionTrainer
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    b = ds.batches[0]
+    cap = b["caption_data"].caption
+    t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-2)
+    t.agent.train()
+    t.capture(b["feature_stacks"], cap, warmup=1)
+    att = t.agent.bm_worker_fus.decoder.layers[0].self_att
+    w = att.linear_Q2d.weight
+    t.agent.eval()
+    greedy_decode(t.agent, b["feature_stacks"], 4, 2, 3, 1, "audio_video")        # creates the decoders' shadow groups
+    before = w.detach().clone()
+    s0 = SHADOWS.weight(w, att.linear_K2d.weight, att.linear_V2d.weight).clone()
+    t.agent.train()
+    for _ in range(3):
+        t.replay()
+    assert float((w.detach() - before).abs().max()) > 1e-3                        # the replays really moved the weight
+    s1 = SHADOWS.weight(w, att.linear_K2d.weight, att.linear_V2d.weight)
+    D = w.shape[0]
+    assert torch.equal(s1[:D, :w.shape[1]], w.detach().to(torch.bfloat16)) and not torch.equal(s0, s1)
+    # and decoding after the training steps equals a decoder built from scratch on the same weights
+    t.agent.eval()
+    toks = greedy_decode(t.agent, b["feature_stacks"], 4, 2, 3, 1, "audio_video")
+    t.agent.__dict__.pop("_incremental_decoders", None)
+    SHADOWS.invalidate()
+    assert torch.equal(toks, greedy_decode(t.agent, b["feature_stacks"], 4, 2, 3, 1, "audio_video"))
