@@ -75,7 +75,11 @@ class ShadowCache:
         ent = self.b.get(key)
         if self._alive(ent, params) and ent[0] == ver:
             return ent[1]
-        buf = torch.cat([p.detach() for p in params])
+        if self._alive(ent, params) and ent[1].device == params[0].device:
+            buf = ent[1]                       # re-made in place: captured graphs (decoder, trainer) keep reading this address
+            torch.cat([p.detach() for p in params], out=buf)
+        else:
+            buf = torch.cat([p.detach() for p in params])
         self.b[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
         return buf
 
