@@ -247,7 +247,10 @@ class IncrementalDecoder:
         concatenated biases are rebuilt) and returns their addresses: a different address means the graph holds a dead
         pointer and is captured again"""
         ws, bs = self._weights()
-        return tuple(SHADOWS.weight(*w).data_ptr() for w in ws) + tuple(SHADOWS.bias(*b).data_ptr() for b in bs)
+        # (+ the parameters the step reads directly -- LayerNorm, biases, embedding table, critic weights: their storages
+        # move when the module is re-materialised, e.g. by .to(device) or by a trainer that re-points them into its bucket)
+        return tuple(SHADOWS.weight(*w).data_ptr() for w in ws) + tuple(SHADOWS.bias(*b).data_ptr() for b in bs) + \
+            tuple(p.data_ptr() for p in self.agent.parameters())
 
     def _capture(self):
         self._shadow_sig = self._shadows()
