@@ -517,14 +517,12 @@ class BMHrlAgent(nn.Module):
 
     def prediction(self, x, trg, mask):
         emb, C = self.emb_C.embed_posenc(trg, self.pos_enc_C)
-        V, A = self._encode(x)
-        return self.predict_with_features(emb, V, A, mask, C)
+        return self.predict_with_features(emb, None, None, mask, C, x=x)      # (the critic is forked before x is encoded)
 
     def mixed_prediction(self, x, trgs, mask, mix_factor):
         y_trg, yhat_trg = trgs
         emb, C = self.emb_C.embed_posenc(y_trg, self.pos_enc_C, yhat_trg, float(mix_factor))
-        V, A = self._encode(x)
-        return self.predict_with_features(emb, V, A, mask, C)
+        return self.predict_with_features(emb, None, None, mask, C, x=x)
 
     # ---- memoised decoding.  The reference's greedy decoders re-run the whole agent -- encoder
     # included -- for every generated token (epoch_loops/captioning_bmrl_loops.py:61-76,127-152); the encoder output and
@@ -542,7 +540,7 @@ class BMHrlAgent(nn.Module):
             mask['_kv_cache'] = kv_cache
         return self.predict_with_features(emb, None, None, mask, C, memory=memory)[0]
 
-    def predict_with_features(self, C_emb, V, A, mask, C=None, memory=None):
+    def predict_with_features(self, C_emb, V, A, mask, C=None, memory=None, x=None):
         # The frozen critic only feeds the segment labels the manager needs at the very end: it runs on a side HIP
         # stream (a parallel branch of the captured graph) next to the encoder / fusion kernels.
         side = None
@@ -557,6 +555,8 @@ class BMHrlAgent(nn.Module):
             segment_labels = self._segment_labels(C_emb)
         if C is None:
             C = self.pos_enc_C(C_emb)
+        if x is not None:                      # raw features: their positional encoding runs after the critic's fork -- the
+            V, A = self._encode(x)             # critic's 45 dependent launches are the longest chain of the forward
         # Va: video stream (B,Tv,d_vid), Av: audio stream (B,Ta,d_aud)
         Va, Av = self.bm_enc((V, A), mask) if memory is None else memory
         # (worker and manager stacks as two parallel branches were measured slower than back to back: 10.8 -> 11.4 ms/step;
