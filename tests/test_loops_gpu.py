@@ -111,11 +111,12 @@ def test_trainer_graph_replay_matches_eager(setup):
     l_graph = [float(t2.replay()) for _ in range(3)]
     assert all(abs(a - g) < 2e-3 * abs(a) for a, g in zip(l_eager[1:], l_graph)), (l_eager, l_graph)
     assert l_eager[3] < l_eager[0]
-    # one rank: the captured Adam pass reads the gradients in place (no gather copy inside the graph) ...
-    plan_ptrs = t2.opt.__dict__["_seg_plan"][2]
-    assert plan_ptrs is not None and sum(p != 0 for p in plan_ptrs) > 100
-    # ... and the flat gradient bucket is not written at all
-    assert float(t2.opt.grad.abs().max()) == 0.0
+    if t2.opt.direct_grads and t2.opt.fused_shadows:          # (the defaults; both have environment switches for A/B runs)
+        # one rank: the captured Adam pass reads the gradients in place (no gather copy inside the graph) ...
+        plan_ptrs = t2.opt.__dict__["_seg_plan"][2]
+        assert plan_ptrs is not None and sum(p != 0 for p in plan_ptrs) > 100
+        # ... and the flat gradient bucket is not written at all
+        assert float(t2.opt.grad.abs().max()) == 0.0
 
 
 def test_trainer_rl_graph_replay_matches_eager(setup):
