@@ -251,6 +251,15 @@ def test_config5_long_segments_forward_vs_oracle(dev):
     _forward_backward_vs_oracle(dev, 2, 1024, 2048, 2, False)
 
 
+def test_config5_long_segments_gradients_vs_oracle(dev):
+    """the same shapes through loss and backward: the fused head-dimension-128 backward at Sk = 2048 (17 tiles per key
+    block, two rounds of workgroups) and the d_k = 256 backward GEMMs at Sq = 2048 against the oracle's autograd"""
+    import time
+    t0 = time.time()
+    _forward_backward_vs_oracle(dev, 2, 1024, 2048, 2, True)
+    print(f"config-5 forward + backward vs oracle: {time.time() - t0:.1f} s")
+
+
 def test_full_batch_consistent_with_oracle_checked_chunks(dev):
     """The bench workload itself (BASELINE config 2: B=16, Tv=256, Ta=800, L=30, V=10172).  The CPU oracle takes minutes at
     this size, so the full batch is tied to the oracle-checked shape (test_full_size_forward_vs_oracle, B=2) through two
