@@ -385,3 +385,62 @@ def test_paired_fusion_stacks_equal_separate_stacks(dev, tiny):
     worst = max((float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-12)), n) for n in gb
                 if float(gb[n].norm()) > 0 and not n.endswith("linear_K2d.bias"))
     assert worst[0] < 5e-3, worst
+
+
+def test_config3_worker_rl_step_full_width_vs_oracle(dev):
+    """BASELINE configs[2] at the config-2 shapes (B=2): the worker RL step's captioning loss -- tokens drawn by the HIP
+    sampler from the HIP path's own log-probs, synthetic rewards, value-head baseline with stabilisation on -- and its
+    gradients against the oracle's worker_rl_loss on the SAME sampled tokens; plus the masked-MSE value loss."""
+    from oracle import bmhrl_oracle as O
+    from bmhrl_amd.epoch_loops.captioning_bmrl_loops import biased_kl
+    from bmhrl_amd.loss.biased_kl import BiasedKL
+    from bmhrl_amd.model.bm_hrl_agent import BMWorkerValueFunction
+    from bmhrl_amd.model.masking import make_masks
+    cfg = syn.default_cfg(dout_p=0.0)
+    V, B, Tv, Ta, L = 10172, 2, 256, 800, 30
+    agent, sd = build_agent(cfg, V, dev)
+    agent.teach_worker()
+    vnet = BMWorkerValueFunction(cfg)
+    vsd = syn.fill_state_dict({k: tuple(v.shape) for k, v in vnet.state_dict().items()}, seed=7)
+    vnet.load_state_dict(vsd); vnet.to(dev)
+    b = syn.synthetic_batch(B, Tv, Ta, L, V, seed=0)
+    cap = b["captions"]
+    trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
+    rewards = syn.synthetic_rewards(B, L, seed=2)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    masks = make_masks(fs, trg_in.to(dev), "audio_video", 1)
+    pred, w_feat, m_feat, goals, seg = agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in.to(dev), masks)
+    loss_mask = (trg_y != 1).to(dev)
+    expected = vnet((w_feat.detach(), goals.detach())).squeeze(-1)
+    rows, scores, sampled, amp = biased_kl(True, pred, None, expected.detach(), trg_y.to(dev), None, loss_mask, seg, dev,
+                                           BiasedKL(0.7, 1), True, reward_fn=lambda s, c: rewards.to(dev), seed=4242)
+    n_tok = loss_mask.sum()
+    loss = torch.sum(rows) / (n_tok * 0.2)
+    vloss = (((expected - scores[0]) ** 2) * loss_mask.float()).mean()
+    (loss + vloss).backward()
+    # oracle on the same sampled tokens
+    watch = [k for k in WATCH if not k.startswith("bm_manager_fus.") and not k.startswith("manager.")]    # (frozen in this phase)
+    sdr = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    ref = O.agent_forward(sdr, cfg, (b["rgb"] + b["flow"], b["audio"]), trg_in, O.make_masks(b["rgb"], b["audio"], trg_in, 1))
+    vsdr = {k: v.clone().requires_grad_(True) for k, v in vsd.items()}
+    ref_exp = O.value_function(vsdr, ref[1].detach()).squeeze(-1)
+    ref_loss = O.worker_rl_loss(ref[0], trg_y, sampled[0].cpu(), rewards, ref_exp.detach(), 0.7, 1, True)
+    score_used = (rewards - ref_exp.detach()) * (trg_y != 1).float()
+    ref_v = O.masked_value_loss(ref_exp, score_used, trg_y != 1)
+    (ref_loss + ref_v).backward()
+    assert rel(loss, ref_loss.detach()) < 2e-3, (float(loss), float(ref_loss))
+    assert rel(vloss, ref_v.detach()) < 1e-2
+    named = dict(agent.named_parameters())
+    worst = 0.0
+    for k in watch:
+        e = rel_l2(named[k].grad, sdr[k].grad)
+        worst = max(worst, e)
+        score_path = ".enc_att_" in k and (k.endswith("linear_K2d.weight") or k.endswith("linear_Q2d.weight"))
+        assert e < (1.5e-1 if score_path else 3e-2), (k, e)
+    # value head: a 300 -> 600 -> 300 -> 1 MLP on bf16 operands; its masked-MSE gradient is a sum over 60 rows of residuals
+    # (expected - target) that are themselves differences of O(1) numbers -- measured 1e-2 .. 6e-2 of the gradient's norm
+    verr = {k: rel_l2(p.grad, vsdr[k].grad) for k, p in vnet.named_parameters()}
+    assert max(verr.values()) < 1e-1, verr
+    assert named["manager.linear.weight"].grad is None                      # frozen in the worker phase
+    print(f"RL step vs oracle: loss {rel(loss, ref_loss.detach()):.2e}, value loss {rel(vloss, ref_v.detach()):.2e}, worst grad {worst:.2e}, "
+          f"value-head grads {({k: round(v, 4) for k, v in verr.items()})}")
