@@ -444,3 +444,53 @@ def test_config3_worker_rl_step_full_width_vs_oracle(dev):
     assert named["manager.linear.weight"].grad is None                      # frozen in the worker phase
     print(f"RL step vs oracle: loss {rel(loss, ref_loss.detach()):.2e}, value loss {rel(vloss, ref_v.detach()):.2e}, worst grad {worst:.2e}, "
           f"value-head grads {({k: round(v, 4) for k, v in verr.items()})}")
+
+
+def test_manager_biased_kl_full_width_vs_oracle(dev):
+    """the manager branch of biased_kl() (reference :299-334: arg-max tokens, score * segments, amplitude from the product of
+    the segment's probabilities, expected scores summed per segment) at the config-2 shapes (B=2), stabilised, against the
+    oracle's manager_biased_kl: loss and the gradients of the manager side (the phase trains bm_manager_fus + manager)."""
+    from oracle import bmhrl_oracle as O
+    from bmhrl_amd.epoch_loops.captioning_bmrl_loops import biased_kl
+    from bmhrl_amd.loss.biased_kl import BiasedKL
+    from bmhrl_amd.model.masking import make_masks
+    cfg = syn.default_cfg(dout_p=0.0, rl_critic_score_threshhold=0.5)
+    V, B, Tv, Ta, L = 10172, 2, 256, 800, 30
+    agent, sd = build_agent(cfg, V, dev)
+    agent.teach_manager()
+    agent.manager.exploration = False                  # (the exploration noise is a torch.randn: not comparable)
+    b = syn.synthetic_batch(B, Tv, Ta, L, V, seed=0)
+    cap = b["captions"]
+    trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
+    rewards = syn.synthetic_rewards(B, L, seed=2)
+    baseline = 0.3 * syn.synthetic_rewards(B, L, seed=5)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    masks = make_masks(fs, trg_in.to(dev), "audio_video", 1)
+    with torch.no_grad():                              # a threshold at the median critic score: both label values occur
+        emb, _ = agent.emb_C.embed_posenc(trg_in.to(dev), agent.pos_enc_C)
+        thr = float(torch.sigmoid(agent.critic.score_and_labels(emb, 0.0)[0]).median())
+    agent.critic_score_threshhold = cfg.rl_critic_score_threshhold = thr
+    pred, w_feat, m_feat, goals, seg = agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in.to(dev), masks)
+    assert 0 < int(seg.sum()) < seg.numel()            # there are segments to multiply over
+    loss_mask = (trg_y != 1).to(dev)
+    rows, scores, sampled, amp = biased_kl(False, pred, None, baseline.to(dev), trg_y.to(dev), None, loss_mask, seg, dev,
+                                           BiasedKL(0.7, 1), True, reward_fn=lambda s, c: rewards.to(dev))
+    loss = torch.sum(rows) / (loss_mask.sum() * 0.2)
+    loss.backward()
+    watch = ["bm_manager_fus.decoder.layers.1.self_att.linear_Q2d.weight", "bm_manager_fus.decoder.layers.0.enc_att_V.linear_V2d.weight",
+             "bm_manager_fus.decoder.layers.1.a_v_constant", "manager.linear.weight"]
+    sdr = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    ref = O.agent_forward(sdr, cfg, (b["rgb"] + b["flow"], b["audio"]), trg_in, O.make_masks(b["rgb"], b["audio"], trg_in, 1))
+    assert np.array_equal(seg.cpu().numpy(), ref[4].numpy())
+    div, ref_score, ref_sampled, ref_amp = O.manager_biased_kl(ref[0], trg_y, rewards, baseline, trg_y != 1, ref[4], 0.7, 1, True)
+    ref_loss = div.sum() / ((trg_y != 1).sum() * 0.2)
+    ref_loss.backward()
+    same = ref_sampled == sampled[0].cpu()
+    assert float(same.float().mean()) > 0.95           # arg-max tokens agree but for bf16 near-ties
+    assert rel(loss, ref_loss.detach()) < (2e-3 if bool(same.all()) else 5e-2), (float(loss), float(ref_loss))
+    named = dict(agent.named_parameters())
+    errs = {k: rel_l2(named[k].grad, sdr[k].grad) for k in watch}
+    if bool(same.all()):
+        assert max(errs.values()) < 3e-2, errs
+    assert named["worker.core.projection.weight"].grad is None          # worker side frozen in the manager phase
+    print(f"manager biased KL vs oracle: loss {rel(loss, ref_loss.detach()):.2e}, arg-max agreement {float(same.float().mean()):.3f}, grads {errs}")
