@@ -151,3 +151,26 @@ def test_validation_1by1_host_side(tmp_path):
     assert out["submission_path"] == str(path)           # no evaluator in this image: the predictions come back
     out2 = validation_1by1_loop(cfg, Model(), Loader(batches), decoder, 3, None)
     assert out2["submission_path"] != str(path) and out2["submission_path"].startswith(str(path)[:-5] + "_")
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r02_bench.json is a verbatim bench.py line: the fields of the driver's contract are all there"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r02_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "caption-train steps/sec" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "bf16" and "workload" in d["config"]
+    assert abs(d["value"] - d["steps"] * d["n_gpus"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_us"] * 1e-6) / 1e12) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
