@@ -21,9 +21,9 @@ def run_smoke():
     assert torch.cuda.is_available(), "smoke() needs cuda:0"
     _lib.load()
     dev = torch.device("cuda:0")
-    cfg = syn.tiny_cfg(d_model=1024, rl_att_heads=4)   # d_k = 256: the flash attention kernel is on the path
+    cfg = syn.default_cfg(dout_p=0.0)                  # the reference widths (1024 / 128 / 300, d_model 1024, H 4, N 2)
     cfg.device = "cuda:0"
-    V, B, Tv, Ta, L = 60, 2, 160, 200, 8
+    V, B, Tv, Ta, L = 300, 2, 160, 200, 10             # Tv >= 128: the fused attention kernels are on the path
     ds = SimpleNamespace(trg_voc_size=V, train_vocab=SimpleNamespace(vectors=None))
     agent = BMHrlAgent(cfg, ds)
     shapes = {k: tuple(v.shape) for k, v in agent.state_dict().items()}
@@ -49,7 +49,7 @@ def run_smoke():
     lerr = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
     g = agent.bm_enc.encoder.layers[0].self_att_M1.linear_Q2d.weight.grad
     assert g is not None and bool(torch.isfinite(g).all())
-    assert err < 1e-3 and lerr < 1e-3 and err_elem < 3e-3, (err, err_elem, lerr)
+    assert err < 1e-3 and lerr < 1e-3 and err_elem < 1e-3, (err, err_elem, lerr)
     print(f"smoke ok: log-prob err {err:.2e} (max-norm) / {err_elem:.2e} (per element, relative, floor 1.0), "
           f"loss rel err {lerr:.2e}, loss {float(loss):.5f}")
 
