@@ -504,7 +504,9 @@ def detr_stack(sd: SD, p: str, n_layers: int, x: Tensor, layer_fn, has_norm: boo
 # --------------------------------------------------------------------------------------
 # host-side RL glue of the reference, restated as the loops they are
 # discontinue_reward_loop is pinned to the reference's own function (tests/golden/rl_glue.npz: metrics/util.py loads
-# without nltk); the two segment loops sit in modules that import nltk and are pinned by reading only.
+# without nltk); the two segment loops and both branches of biased_kl are pinned to outputs of the reference's own
+# epoch_loops/captioning_bmrl_loops.py:biased_kl and metrics/batched_meteor.py:segment_reward (tests/golden/rl_loops.npz,
+# made by tests/golden/make_golden.py:rl_loops_cases; tests/test_oracle_golden.py::test_biased_kl_loops_against_the_reference).
 # --------------------------------------------------------------------------------------
 def manager_segment_loop(sampled_probs: Tensor, expected_scores: Tensor, segments: Tensor) -> Tuple[Tensor, Tensor]:
     """epoch_loops/captioning_bmrl_loops.py:301-316 (manager branch of biased_kl): per segment (positions after the

@@ -304,8 +304,7 @@ def detr_cases():
 
 def rl_glue_cases():
     """metrics/util.py:discontinue_reward (the file imports only torch, so it is loaded by path; its package pulls nltk).
-    The segment loops of metrics/batched_meteor.py and epoch_loops/captioning_bmrl_loops.py import nltk at module level
-    and cannot be executed here: their restatements in oracle/ are pinned by reading only."""
+    The segment loops of metrics/batched_meteor.py and epoch_loops/captioning_bmrl_loops.py are run by rl_loops_cases()."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("ref_metrics_util", os.path.join(REF, "metrics", "util.py"))
     ref = importlib.util.module_from_spec(spec)
@@ -328,6 +327,95 @@ def rl_glue_cases():
         n += 1
     out["n"] = np.array(n)
     np.savez_compressed(os.path.join(HERE, "rl_glue.npz"), **out)
+
+
+def import_reference_loops():
+    """epoch_loops/captioning_bmrl_loops.py and metrics/batched_meteor.py import nltk at module level (absent in this
+    image) although none of the functions run here touches it: empty modules of that name let the imports pass.  Nothing
+    of nltk is restated -- every attribute the import lines ask for is None."""
+    import importlib
+    import types
+    for name in ("nltk", "nltk.corpus", "nltk.translate", "nltk.translate.meteor_score", "nltk.tokenize", "nltk.tokenize.treebank"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["nltk"].corpus = sys.modules["nltk.corpus"]
+    sys.modules["nltk.corpus"].wordnet = None
+    sys.modules["nltk.translate"].meteor = None
+    sys.modules["nltk.translate.meteor_score"].meteor_score = None
+    sys.modules["nltk.translate.meteor_score"].single_meteor_score = None
+    sys.modules["nltk.tokenize.treebank"].TreebankWordDetokenizer = None
+    return importlib.import_module("epoch_loops.captioning_bmrl_loops"), importlib.import_module("metrics.batched_meteor")
+
+
+class GivenScore:
+    """Scorer stand-in for get_score (captioning_bmrl_loops.py:219-230): type "CIDER", returns the (B, L) reward it was
+    given -- BASELINE configs[2] stubs the rewards the same way."""
+    type = "CIDER"
+
+    def __init__(self, score):
+        self.score = score
+
+    def delta_cider_worker(self, tokens, caption):
+        return self.score.clone(), None
+
+    def delta_cider_manager(self, tokens, caption, mask, segments):
+        return self.score.clone(), None
+
+
+def rl_loops_cases():
+    """The reference's OWN biased_kl (captioning_bmrl_loops.py:271-334), both branches and both `stabilize` values, its
+    get_norm_reward_factor (:414-416) and metrics/batched_meteor.py:segment_reward (:19-36) on random cases incl. rows
+    without a segment (row 0 among them), padded rows, adjacent segment ends and a batch with no segment at all."""
+    from loss.biased_kl import BiasedKL
+    loops, meteor = import_reference_loops()
+    g = torch.Generator().manual_seed(29)
+    out = {}
+    n = 0
+    for i in range(40):
+        B = int(torch.randint(1, 6, (1,), generator=g))
+        L = int(torch.randint(2, 10, (1,), generator=g))
+        V = int(torch.randint(7, 30, (1,), generator=g))
+        logits = 2.0 * torch.randn(B, L, V, generator=g)
+        trg = torch.randint(2, V, (B, L), generator=g)
+        for b in range(B):
+            if float(torch.rand(1, generator=g)) < 0.5:
+                trg[b, int(torch.randint(1, L, (1,), generator=g)):] = 1
+        seg = (torch.rand(B, L, generator=g) < 0.4).int()
+        if i % 4 == 0:
+            seg[0] = 0
+        if i % 7 == 3 and B > 2:
+            seg[1] = 0
+        if i == 13:
+            seg[:] = 0
+        if i % 5 == 2:
+            seg[-1, :2] = 1
+        score = torch.rand(B, L, generator=g)
+        baseline = torch.rand(B, L, generator=g) * 0.6
+        mask = trg != 1
+        stab = bool(i % 2)
+        out.update({f"logits{i}": np_(logits), f"trg{i}": np_(trg), f"seg{i}": np_(seg), f"score{i}": np_(score),
+                    f"base{i}": np_(baseline), f"stab{i}": np.array(stab)})
+        crit = BiasedKL(0.7, 1)
+        with contextlib.redirect_stderr(io.StringIO()):
+            # manager branch
+            x = logits.clone().requires_grad_(True)
+            div, sc, tok, _ = loops.biased_kl(False, torch.log_softmax(x, -1), GivenScore(score), baseline.clone(), trg, None, mask, seg,
+                                              "cpu", crit, stab)
+            div.sum().backward()
+            out.update({f"m_div{i}": np_(div), f"m_score{i}": np_(sc[0]), f"m_tok{i}": np_(tok[0]), f"m_grad{i}": np_(x.grad)})
+            # worker branch: the sample is drawn from torch's global generator (Categorical.sample)
+            x = logits.clone().requires_grad_(True)
+            torch.manual_seed(1000 + i)
+            div, sc, tok, _ = loops.biased_kl(True, torch.log_softmax(x, -1), GivenScore(score), baseline.clone(), trg, None, mask, seg,
+                                              "cpu", crit, stab)
+            div.sum().backward()
+            out.update({f"w_div{i}": np_(div), f"w_score{i}": np_(sc[0]), f"w_tok{i}": np_(tok[0]), f"w_grad{i}": np_(x.grad)})
+        out[f"nf_w{i}"] = np_(loops.get_norm_reward_factor(True, mask, seg))
+        out[f"nf_m{i}"] = np_(loops.get_norm_reward_factor(False, mask, seg))
+        sr, sidx = meteor.segment_reward(score, seg)
+        out[f"sr{i}"], out[f"sr_idx{i}"] = np_(sr), np_(sidx)
+        n += 1
+    out["n"] = np.array(n)
+    np.savez_compressed(os.path.join(HERE, "rl_loops.npz"), **out)
 
 
 def loader_clip_arrays(i):
@@ -443,6 +531,9 @@ if __name__ == "__main__":
     if "--only-value" in sys.argv:
         value_function_cases()
         sys.exit(0)
+    if "--only-rl-loops" in sys.argv:
+        rl_loops_cases()
+        sys.exit(0)
     if "--only-sample" in sys.argv:
         sample_clip_decode()
         sys.exit(0)
@@ -454,6 +545,7 @@ if __name__ == "__main__":
     sample_clip_decode()
     detr_cases()
     rl_glue_cases()
+    rl_loops_cases()
     loader_cases()
     value_function_cases()
     for f in sorted(os.listdir(HERE)):

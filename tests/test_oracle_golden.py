@@ -224,3 +224,41 @@ def test_value_functions_match_the_reference(golden):
             ref = torch.from_numpy(z[f"d{d}/{name}/out"])
             assert out.shape == ref.shape == (3, 6, 1)
             assert float((out - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_biased_kl_loops_against_the_reference(golden):
+    """tests/golden/rl_loops.npz holds outputs of the reference's OWN epoch_loops/captioning_bmrl_loops.py:biased_kl (both
+    branches, run with given rewards), get_norm_reward_factor and metrics/batched_meteor.py:segment_reward: the oracle's
+    manager_biased_kl / manager_segment_loop / worker_biased_kl / segment_reward_loop are pinned to them."""
+    g = golden("rl_loops")
+    n = int(g["n"])
+    assert n >= 40
+    seen_empty_row0 = seen_no_segment = False
+    for i in range(n):
+        logits, trg, seg = T(g[f"logits{i}"]), T(g[f"trg{i}"]), T(g[f"seg{i}"])
+        score, base, stab = T(g[f"score{i}"]), T(g[f"base{i}"]), bool(g[f"stab{i}"])
+        mask = trg != 1
+        seen_empty_row0 |= int(seg[0].sum()) == 0 and int(seg.sum()) > 0
+        seen_no_segment |= int(seg.sum()) == 0
+        # manager branch
+        x = logits.clone().requires_grad_(True)
+        div, sc, tok, _ = O.manager_biased_kl(torch.log_softmax(x, -1), trg, score, base, mask, seg, 0.7, 1, stab)
+        div.sum().backward()
+        assert torch.equal(tok, T(g[f"m_tok{i}"]))
+        close(div, g[f"m_div{i}"], 1e-5)
+        close(sc, g[f"m_score{i}"], 1e-6)
+        close(x.grad, g[f"m_grad{i}"], 1e-5)
+        # worker branch on the tokens the reference drew
+        x = logits.clone().requires_grad_(True)
+        div, sc = O.worker_biased_kl(torch.log_softmax(x, -1), trg, T(g[f"w_tok{i}"]), score, base, mask, 0.7, 1, stab)
+        div.sum().backward()
+        close(div, g[f"w_div{i}"], 1e-5)
+        close(sc, g[f"w_score{i}"], 1e-6)
+        close(x.grad, g[f"w_grad{i}"], 1e-5)
+        # norm factors (:414-416) as the oracle forms them inside the two branches
+        assert torch.equal(mask.sum(-1).reshape(-1, 1), T(g[f"nf_w{i}"]))
+        assert torch.equal(seg.sum(-1).reshape(-1, 1), T(g[f"nf_m{i}"]))
+        sr, idx = O.segment_reward_loop(score, seg)
+        close(sr, g[f"sr{i}"], 1e-6)
+        assert torch.equal(idx, T(g[f"sr_idx{i}"]))
+    assert seen_empty_row0 and seen_no_segment

@@ -63,3 +63,14 @@ def test_discontinue_reward_oracle_and_vectorised_match_reference_fixture(golden
         for fn in (O.discontinue_reward_loop, G.discontinue_reward):
             assert torch.allclose(fn(x.clone(), gamma, n_step), T(g[f"plain{i}"]), rtol=1e-5, atol=1e-6), (fn, i)
             assert torch.allclose(fn(x.clone(), gamma, n_step, seg), T(g[f"segd{i}"]), rtol=1e-5, atol=1e-6), (fn, i)
+
+
+def test_vectorised_segment_glue_matches_reference_fixture(golden):
+    """tests/golden/rl_loops.npz: the reference's own segment_reward (metrics/batched_meteor.py:19-36); the manager
+    segment products of rl_glue are covered through the oracle, which the same file pins."""
+    g = golden("rl_loops")
+    T = torch.from_numpy
+    for i in range(int(g["n"])):
+        score, seg = T(g[f"score{i}"]), T(g[f"seg{i}"])
+        a, idx = G.segment_reward(score, seg)
+        assert torch.allclose(a, T(g[f"sr{i}"]), rtol=1e-5, atol=1e-6) and torch.equal(idx, T(g[f"sr_idx{i}"]))
