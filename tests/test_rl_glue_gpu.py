@@ -68,3 +68,39 @@ def test_manager_branch_of_biased_kl_matches_the_oracle(stabilize):
     assert torch.allclose(rows.view(-1).detach().cpu(), ref_rows.detach(), atol=1e-4, rtol=1e-4)
     gerr = (lp.grad.cpu() - ref_lp.grad).abs().max() / ref_lp.grad.abs().max()
     assert float(gerr) < 1e-4, float(gerr)
+
+
+def test_biased_kl_against_the_reference_fixture(golden):
+    """tests/golden/rl_loops.npz: outputs of the reference's own biased_kl (epoch_loops/captioning_bmrl_loops.py:271-334).
+    Manager branch end to end (arg-max tokens, score, divergence rows, gradient w.r.t. the logits); worker branch through
+    BiasedKL.biased_kl_from_score on the tokens the reference drew (its sample comes from torch's global generator)."""
+    from bmhrl_amd.epoch_loops.captioning_bmrl_loops import biased_kl
+    from bmhrl_amd.loss.biased_kl import BiasedKL
+    dev = torch.device("cuda:0")
+    g = golden("rl_loops")
+    T = torch.from_numpy
+    crit = BiasedKL(0.7, 1)
+    for i in range(int(g["n"])):
+        logits, trg, seg = T(g[f"logits{i}"]).to(dev), T(g[f"trg{i}"]).to(dev), T(g[f"seg{i}"]).to(dev)
+        score, base, stab = T(g[f"score{i}"]).to(dev), T(g[f"base{i}"]).to(dev), bool(g[f"stab{i}"])
+        mask = trg != 1
+        x = logits.clone().requires_grad_(True)
+        rows, sc, tok, _ = biased_kl(False, torch.log_softmax(x, -1), None, base.clone(), trg, None, mask, seg, dev, crit, stab,
+                                     reward_fn=lambda a, c: score)
+        rows.sum().backward()
+        assert torch.equal(tok[0].cpu(), T(g[f"m_tok{i}"])), i
+        assert torch.allclose(sc[0].cpu(), T(g[f"m_score{i}"]), atol=1e-6), i
+        ref_rows = T(g[f"m_div{i}"]).sum(-1)
+        assert torch.allclose(rows.view(-1).detach().cpu(), ref_rows, atol=2e-5, rtol=1e-4), i
+        rg = T(g[f"m_grad{i}"])
+        assert float((x.grad.cpu() - rg).abs().max()) <= 1e-4 * max(float(rg.abs().max()), 1e-3), i
+        # worker branch, given tokens
+        x = logits.clone().requires_grad_(True)
+        w_tok = T(g[f"w_tok{i}"]).to(dev)
+        s = (score - base) * mask.float() if stab else score
+        n_row = mask.sum(-1, keepdim=True).float().expand_as(trg)
+        rows, _ = crit.biased_kl_from_score(torch.log_softmax(x, -1), trg, w_tok, s, n_row)
+        rows.sum().backward()
+        assert torch.allclose(rows.view(-1).detach().cpu(), T(g[f"w_div{i}"]).sum(-1), atol=2e-5, rtol=1e-4), i
+        rg = T(g[f"w_grad{i}"])
+        assert float((x.grad.cpu() - rg).abs().max()) <= 1e-4 * max(float(rg.abs().max()), 1e-3), i
