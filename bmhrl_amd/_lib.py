@@ -54,6 +54,7 @@ PROTOTYPES = {
     "bmhrl_attention_shared128_bwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, i32, ptr, i32, i32,
                                       i32, i32, f32, ptr],
     "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, ptr],
+    "bmhrl_softmax_bwd_rows": [ptr, i64, ptr, i64, ptr, i64, i64, i32, f32, ptr, i64, i64, i32, i32, ptr],
     "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
@@ -62,6 +63,7 @@ PROTOTYPES = {
     "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
     "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr],
+    "bmhrl_cast_split3_bf16": [ptr, i64, ptr, i64, i64, i32, i64, i32, ptr],
     "bmhrl_cast_colsum_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, ptr],
     "bmhrl_cast_colsum_bf16_groups": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, i64, i64, ptr],
     "bmhrl_cast_segments": [ptr, i32, i32, ptr],

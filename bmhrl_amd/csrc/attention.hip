@@ -58,6 +58,29 @@ __global__ void softmax_rows_kernel(const float* __restrict__ S, long lds, bf16_
   for (int c = lane; c < cols; c += 64) pr[c] = (bf16_t)(__expf(s[c] - m) * inv);
 }
 
+// Row softmax backward for the same path: dS[c] = scale * P[c] * (dP[c] - sum_k P[k] dP[k]), one wave per row.  The row term
+// is formed from the SAME bf16 probabilities and fp32 dP the product uses, so the rows of dS sum to (almost) zero whatever
+// rounding P carries -- with the row term taken from the rounded context instead (sum_d dO O), the few-query attentions over a
+// long memory lost 3 % of their score gradient (30 queries, 256 / 800 keys: dQ' = dS mem is what is left of a cancellation).
+__global__ void softmax_bwd_rows_kernel(const bf16_t* __restrict__ P, long ldp, const float* __restrict__ dP, long lddp,
+                                        bf16_t* __restrict__ dS, long ldds, long rows, int cols, float scale,
+                                        const uint8_t* __restrict__ mask, long mask_sb, long mask_sq, int rows_per_query,
+                                        int queries) {
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const bf16_t* p = P + row * ldp;
+  const float* g = dP + row * lddp;
+  float acc = 0.f;
+  for (int c = lane; c < cols; c += 64) acc = fmaf((float)p[c], g[c], acc);
+  const float delta = wave_sum(acc);
+  bf16_t* o = dS + row * ldds;
+  // masked_fill: the score of a masked key is a constant, no gradient reaches it (only a fully masked row has P != 0 there)
+  const long q = row / rows_per_query;
+  const uint8_t* m = mask ? mask + (q / queries) * mask_sb + (q % queries) * mask_sq : nullptr;
+  for (int c = lane; c < cols; c += 64) o[c] = (m && !m[c]) ? (bf16_t)0.f : (bf16_t)(scale * (float)p[c] * (g[c] - delta));
+}
+
 int g_cfg256 = 0;   // (QW, KW) split: 0 = automatic; bmhrl_attention_config() pins one (tuning aid)
 
 }  // namespace
@@ -91,6 +114,18 @@ extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int
   else if (dk <= 256) BMHRL_DELTA(2);
   else BMHRL_DELTA(1);
 #undef BMHRL_DELTA
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lddp, void* dS, int64_t ldds,
+                                      int64_t rows, int32_t cols, float scale, const uint8_t* mask, int64_t mask_sb,
+                                      int64_t mask_sq, int32_t rows_per_query, int32_t queries, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(P && dP && dS && rows > 0 && cols > 0 && ldp >= cols && lddp >= cols && ldds >= cols);
+  BMHRL_CHECK_ARG(!mask || (rows_per_query > 0 && queries > 0 && rows % ((int64_t)rows_per_query * queries) == 0));
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)P, (long)ldp, dP, (long)lddp,
+                     (bf16_t*)dS, (long)ldds, (long)rows, cols, scale, mask, (long)mask_sb, (long)mask_sq,
+                     mask ? rows_per_query : 1, mask ? queries : 1);
   return hip_status(hipGetLastError());
 }
 

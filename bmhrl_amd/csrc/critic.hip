@@ -367,12 +367,15 @@ extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_laye
     tab.l[i] = p;
   }
   static const int spt = getenv("BMHRL_RNN_SPT") ? atoi(getenv("BMHRL_RNN_SPT")) : 2;     // gate rows per thread (tuning aid: 1)
+  static const bool vargrid = getenv("BMHRL_RNN_VARGRID") && atoi(getenv("BMHRL_RNN_VARGRID")) != 0;
   const int ubw = UB * (spt == 1 ? 1 : 2);
   const unsigned nb16 = (unsigned)((B + 15) / 16);
   for (int s = 0; s < L + chunk * (n_layers - 1); ++s) {
     // launches in which the layers start a chunk (every layer trails the one below by `chunk` steps, so they all do in the
     // same launches) carry the extra projection roles
-    const unsigned roles = (unsigned)chunk;            // (the same grid in every launch; the extra roles of a non-chunk launch exit at once)
+    // (the same grid in every launch; the extra roles of a non-chunk launch exit at once.  BMHRL_RNN_VARGRID=1 launches the
+    // role blocks on chunk steps only -- the r02 form, kept as a diagnostic switch: see DESIGN.md section 10)
+    const unsigned roles = (vargrid && !(chunk > 1 && s % chunk == 0)) ? 1u : (unsigned)chunk;
     dim3 grid((unsigned)((H + ubw - 1) / ubw), nb16 * roles, (unsigned)n_layers), block(256);
     if (spt == 1) hipLaunchKernelGGL(rnn_wave_kernel<1>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);
     else hipLaunchKernelGGL(rnn_wave_kernel<2>, grid, block, 0, S_(stream), tab, n_layers, B, L, H, s, chunk);

@@ -349,9 +349,29 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* 
   }
 }
 
+// Split operand: x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  Three column blocks of width `part` at y: block 0 = hi,
+// block lo_slot (1 or 2) = lo, the remaining block = hi again.  An activation laid out [hi | hi | lo] against a weight laid out
+// [hi | lo | hi] gives x_hi W_hi + x_hi W_lo + x_lo W_hi in ONE GEMM with K = 3 part: the product to ~16 mantissa bits (the
+// lo x lo term, 2^-18 relative, is dropped).  Used for the vocabulary projection, whose logits carry north_star's 1e-3 bound.
+__global__ void cast_split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long part, int lo_slot,
+                                   long rows, int cols) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % cols;
+    const long r = i / cols;
+    const float v = x[r * ldx + c];
+    const bf16_t hi = (bf16_t)v;
+    bf16_t* o = y + r * ldy + c;
+    o[0] = hi;
+    o[lo_slot * part] = (bf16_t)(v - (float)hi);
+    o[(3 - lo_slot) * part] = hi;
+  }
+}
+
 // Many (rows, cols) fp32 matrices -> bf16 (padded leading dimension) or fp32 copies, ONE launch: the per-step refresh
 // of all bf16 weight shadows and concatenated biases.  seg = 6 int64 per segment: source address, destination address,
-// rows, cols, destination leading dimension (elements; <= 0: the destination is fp32, tightly packed), first block.
+// rows, cols, destination leading dimension (elements; <= 0: the destination is fp32, tightly packed; bits 32.. = `part` > 0: the
+// destination is a split shadow, bf16(x) at column c and c + 2 part, bf16(x - bf16(x)) at c + part), first block.
 // A block owns 4096 consecutive elements of one segment and finds it by bisection over the first-block column.
 constexpr int SEG_WORDS = 6, SEG_ELEMS_PER_BLOCK = 4096;
 __global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg) {
@@ -362,7 +382,8 @@ __global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg)
   }
   const int64_t* e = seg + lo * SEG_WORDS;
   const float* __restrict__ src = reinterpret_cast<const float*>(e[0]);
-  const long rows = e[2], cols = e[3], ldd = e[4];
+  const long rows = e[2], cols = e[3];
+  const long ldd = e[4] <= 0 ? e[4] : (e[4] & 0xffffffffL), part = e[4] <= 0 ? 0 : (e[4] >> 32);
   const long total = rows * cols;
   const long base = ((long)blockIdx.x - e[5]) * SEG_ELEMS_PER_BLOCK;
   if (ldd <= 0) {
@@ -371,6 +392,17 @@ __global__ void cast_segments_kernel(const int64_t* __restrict__ seg, int n_seg)
     return;
   }
   bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(e[1]);
+  if (part) {                                          // split shadow [hi | lo | hi] (see bmhrl_cast_split3_bf16)
+    for (long i = base + threadIdx.x; i < base + SEG_ELEMS_PER_BLOCK && i < total; i += blockDim.x) {
+      const long r = i / cols, c = i - r * cols;
+      const float v = src[i];
+      const bf16_t hi = (bf16_t)v;
+      dst[r * ldd + c] = hi;
+      dst[r * ldd + part + c] = (bf16_t)(v - (float)hi);
+      dst[r * ldd + 2 * part + c] = hi;
+    }
+    return;
+  }
   if ((cols & 3) == 0 && (ldd & 3) == 0 && ((e[0] | e[1]) & 15) == 0) {      // 16-byte loads, 8-byte stores
     for (long i = base + 4 * threadIdx.x; i < base + SEG_ELEMS_PER_BLOCK && i < total; i += 4 * blockDim.x) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
@@ -587,7 +619,8 @@ __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg,
     if (seg[mid * ADAM_WORDS + 5] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const int64_t* e = seg + lo * ADAM_WORDS;
-  const long off = e[0], rows = e[2], cols = e[3], ldd = e[4];
+  const long off = e[0], rows = e[2], cols = e[3];
+  const long ldd = e[4] <= 0 ? e[4] : (e[4] & 0xffffffffL), part = e[4] <= 0 ? 0 : (e[4] >> 32);   // part: split shadow, as cast_segments
   g = e[6] ? reinterpret_cast<const float*>(e[6]) - off : g;        // (indexed with off + i below)
   const long total = rows * cols;
   const long base = ((long)blockIdx.x - e[5]) * SEG_ELEMS_PER_BLOCK;
@@ -615,6 +648,17 @@ __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg,
     return;
   }
   bf16_t* __restrict__ dst = reinterpret_cast<bf16_t*>(e[1]);
+  if (part) {
+    for (long i = base + threadIdx.x; i < end; i += blockDim.x) {
+      const long r = i / cols, c = i - r * cols;
+      const float pn = upd(i);
+      const bf16_t hi = (bf16_t)pn;
+      dst[r * ldd + c] = hi;
+      dst[r * ldd + part + c] = (bf16_t)(pn - (float)hi);
+      dst[r * ldd + 2 * part + c] = hi;
+    }
+    return;
+  }
   if ((cols & 3) == 0 && (ldd & 3) == 0 && (off & 3) == 0 && (e[1] & 7) == 0 && (e[6] & 15) == 0) {     // 16-byte accesses of the four arrays
     for (long i = base + 4 * threadIdx.x; i < end; i += 4 * blockDim.x) {
       f32x4 gv = *reinterpret_cast<const f32x4*>(g + off + i);
@@ -834,6 +878,14 @@ extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy
 extern "C" int bmhrl_cast_colsum_bf16_groups(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols,
                                              float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                              float* colsum, int64_t group_rows, int64_t colsum_stride, bmhrl_stream_t stream);
+
+extern "C" int bmhrl_cast_split3_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part, int32_t lo_slot,
+                                      int64_t rows, int32_t cols, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && part >= cols && ldy >= 3 * part && (lo_slot == 1 || lo_slot == 2));
+  hipLaunchKernelGGL(cast_split3_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y, (long)ldy,
+                     (long)part, lo_slot, (long)rows, cols);
+  return hip_status(hipGetLastError());
+}
 
 extern "C" int bmhrl_cast_colsum_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
                                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* colsum,

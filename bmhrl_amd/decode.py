@@ -238,7 +238,7 @@ class IncrementalDecoder:
                     bs += [(m.linear_K2d.bias, m.linear_V2d.bias)]
         g = ag.worker.goal_attention
         ws += [(g.linear_Q2d.weight,), (g.linear_K2d.weight, g.linear_V2d.weight), (g.linear_d2Q.weight,),
-               (ag.worker.core.projection.weight,), (ag.manager.linear.weight,)]
+               (ag.manager.linear.weight,)]
         bs += [(g.linear_K2d.bias, g.linear_V2d.bias)]
         return ws, bs
 
@@ -250,6 +250,7 @@ class IncrementalDecoder:
         # (+ the parameters the step reads directly -- LayerNorm, biases, embedding table, critic weights: their storages
         # move when the module is re-materialised, e.g. by .to(device) or by a trainer that re-points them into its bucket)
         return tuple(SHADOWS.weight(*w).data_ptr() for w in ws) + tuple(SHADOWS.bias(*b).data_ptr() for b in bs) + \
+            (SHADOWS.weight_split3(self.agent.worker.core.projection.weight).data_ptr(),) + \
             tuple(p.data_ptr() for p in self.agent.parameters())
 
     def _capture(self):

@@ -28,6 +28,7 @@ class ShadowCache:
     def __init__(self):
         self.w = {}
         self.b = {}
+        self.split = {}          # key -> block width of the entries of self.w that are [hi | lo | hi] split shadows
         self.epoch = 0
 
     def invalidate(self):
@@ -65,6 +66,30 @@ class ShadowCache:
             ops.cast_bf16(p.detach(), K, buf, ld, p.shape[0], K, y_off=off * ld)
             off += p.shape[0]
         self.w[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+        return buf
+
+    @staticmethod
+    def split_part(K: int) -> int:
+        """column-block width of a split shadow: K rounded up to the GEMM's 64-wide k-step"""
+        return (K + 63) & ~63
+
+    def weight_split3(self, p):
+        """[hi | lo | hi] bf16 shadow of ONE fp32 weight (N, K) -> (N, 3 * split_part(K)): hi = bf16(w), lo = bf16(w - hi)
+        (ops.cast_split3_bf16, lo_slot 1).  Lives in the same table as the plain shadows under the key (id(p), -3); the
+        refresh / Adam passes find the split layout in `self.split` and write all three blocks."""
+        key = (id(p), -3)
+        ver = self._version((p,), 1, key)
+        ent = self.w.get(key)
+        if not self._alive(ent, (p,)):
+            ent = None
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        N, K = p.shape
+        part = self.split_part(K)
+        buf = ent[1] if ent is not None and ent[1].device == p.device else torch.zeros(N, 3 * part, dtype=_BF16, device=p.device)
+        ops.cast_split3_bf16(p.detach(), K, buf, 3 * part, part, 1, N, K)
+        self.w[key] = (ver, buf, (weakref.ref(p),))
+        self.split[key] = part
         return buf
 
     def bias(self, *params):
@@ -120,7 +145,7 @@ class ShadowCache:
                 for p in params:
                     if kind:      # weight: (N_p, K) fp32 -> rows [off, off + N_p) of the (N, ld) bf16 shadow
                         n, kk, ld = p.shape[0], p.shape[1], buf.shape[1]
-                        rows_.append([p.data_ptr(), buf.data_ptr() + 2 * off * ld, n, kk, ld, blk])
+                        rows_.append([p.data_ptr(), buf.data_ptr() + 2 * off * ld, n, kk, ld | (self.split.get(k, 0) << 32), blk])
                         off += n
                         blk += (n * kk + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
                     else:         # bias: fp32 copy into the concatenated vector
@@ -227,6 +252,19 @@ class StepScratch:
         if self.armed:
             self.memo[key] = (weakref.ref(t), buf)
         return buf
+
+    def zeroed_bf16(self, rows: int, cols: int, device) -> torch.Tensor:
+        """(rows, cols) bf16 buffer that was zero when created and whose users only ever write the same body columns
+        (pooled inside a step like bf16(); a fresh zero tensor outside)"""
+        if not self.armed:
+            return torch.zeros(rows, cols, dtype=_BF16, device=device)
+        key = (rows, cols, device, "z")
+        lst = self.pool.setdefault(key, [])
+        i = self.cursor.get(key, 0)
+        if i == len(lst):
+            lst.append(torch.zeros(rows, cols, dtype=_BF16, device=device))
+        self.cursor[key] = i + 1
+        return lst[i]
 
     def bf16(self, rows: int, cols: int, device) -> torch.Tensor:
         if cols % 8 == 0 or not self.armed:
@@ -605,12 +643,12 @@ class MemAttnFn(torch.autograd.Function):
         ops.gemm(Ob, w_o, rows, dq, D, lda=D, ldb=w_o.shape[1], C_f32=y, ldc=dq, bias=bo.detach(), residual=x, ldr=dq,
                  dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
         ctx.save_for_backward(x, ln_w, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, wq, wk, wv, wo, m8, *stats)
-        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb)
+        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb, msq)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb = ctx.cfg
+        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb, msq = ctx.cfg
         x, ln_w, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, wq, wk, wv, wo, m8 = ctx.saved_tensors[:15]
         stats = ctx.saved_tensors[15:]
         dev = dy.device
@@ -636,9 +674,13 @@ class MemAttnFn(torch.autograd.Function):
         dCx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
         ops.gemm(dOb, w_v, rows, dm, dk, lda=D, ldb=w_v.shape[1], b_trans=True, batch=(1, H), a_strides=(0, dk),
                  b_strides=(0, dk * w_v.shape[1]), C_bf16=dCx, ldcb=H * dmp, cb_strides=(0, dmp))
-        # softmax backward: delta = sum_k P dP = sum_n dCx Cx ; dS = P (dP - delta) * scale with dP = dCx_h mem^T
-        delta = torch.empty(B, H, L, device=dev)
-        ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B, H, L, dmp)
+        # softmax backward: dS = P (dP - delta) * scale with dP = dCx_h mem^T and delta = sum_k P dP.  The fused kernels take
+        # delta = sum_n dCx Cx (the same number through the context); the materialised few-query path forms it from P and dP
+        # themselves (ops.softmax_bwd_rows), which keeps the rows of dS summing to zero under bf16 rounding
+        delta = None
+        if flash:
+            delta = torch.empty(B, H, L, device=dev)
+            ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B, H, L, dmp)
         dQp = zeros(rows, H * dmp, dtype=_BF16, device=dev)
         dmem = None
         dxn = None
@@ -663,11 +705,15 @@ class MemAttnFn(torch.autograd.Function):
                 ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
                          b_strides=(Sk * dmp, 0), C_bf16=P, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_PROB, alpha=scale,
                          mask=m8, mask_sb1=msb, mask_sm=0, rowvec=stats[0], rowvec2=stats[1], rv_strides=(H * L, L))
+                ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
+                         b_strides=(Sk * dmp, 0), C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale,
+                         rowvec=delta, rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
             else:
                 P = stats[0]
-            ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
-                     C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
-                     rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
+                dP = torch.empty(B, L, H, Skp, device=dev)
+                ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
+                         b_strides=(Sk * dmp, 0), C_f32=dP, ldc=H * Skp, c_strides=pstr)
+                ops.softmax_bwd_rows(P, Skp, dP, Skp, dS, Skp, B * L * H, Sk, scale, m8, msb, msq, H, L)
             # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h : two GEMMs with K = L*H (rows (l, h) of the (B, L, H, .) tensors)
             def grad_mem(target, first_accumulates):
                 ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B, 1),
@@ -808,13 +854,13 @@ class PairMemAttnFn(torch.autograd.Function):
         dCx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
         ops.gemm(dOb, w_v, R, dm, dk, lda=D, ldb=ldv, b_trans=True, batch=(2, H), a_strides=(R * D, dk), b_strides=(D * ldv, dk * ldv),
                  C_bf16=dCx, ldcb=H * dmp, cb_strides=(R * H * dmp, dmp))
-        delta = torch.empty(B2, H, L, device=dev)
-        ops.attn_delta(dCx, H * dmp, Cx, H * dmp, delta, B2, H, L, dmp)
+        # dS = scale * P (dP - sum_k P dP), the row term from P and dP themselves (see MemAttnFn.backward)
         dS = _padded_bf16(B2 * L * H, Sk, dev).view(B2, L, H, Skp)
         pstr = (L * H * Skp, Skp)
+        dP = torch.empty(B2, L, H, Skp, device=dev)
         ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B2, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
-                 C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta,
-                 rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
+                 C_f32=dP, ldc=H * Skp, c_strides=pstr)
+        ops.softmax_bwd_rows(P, Skp, dP, Skp, dS, Skp, B2 * L * H, Sk, scale, m8, msb, msq, H, L)
 
         def grad_mem(target, first_accumulates):      # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h, b over the 2 B samples
             ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B2, 1),
@@ -1277,7 +1323,10 @@ class ExpandGoalsFn(torch.autograd.Function):
 
 class WorkerHeadFn(torch.autograd.Function):
     """log_softmax( Linear_{(d_in+d_goal) -> V}( cat[x, goal_completion] ) ) -- model/bm_hrl_agent.py:483-484,463-466.
-    The concatenation only exists as the bf16 GEMM operand; logits / log-probs stay fp32."""
+    The concatenation only exists as the bf16 GEMM operand; logits / log-probs stay fp32.  The log-probs are what north_star
+    bounds (1e-3 relative) and plain bf16 operands of this last product alone cost 6.6e-4 of it (0.3 % operand rounding over
+    K = 364 against |log p| ~ 9), so both operands are split hi + lo: activation [x_hi | x_hi | x_lo] against the weight shadow
+    [W_hi | W_lo | W_hi] (ShadowCache.weight_split3), ONE GEMM with K = 3 * 384.  Backward uses the hi blocks only."""
 
     @staticmethod
     def forward(ctx, x, gc, w, b):
@@ -1285,13 +1334,14 @@ class WorkerHeadFn(torch.autograd.Function):
         B, L, d1 = x.shape
         d2 = gc.shape[-1]
         rows, K, V = B * L, d1 + d2, w.shape[0]
-        xb = SCRATCH.bf16(rows, K, dev)
-        ld = xb.shape[1]
-        ops.cast_bf16(x.contiguous(), d1, xb, ld, rows, d1)
-        ops.cast_bf16(gc.contiguous(), d2, xb, ld, rows, d2, y_off=d1)
-        wb = SHADOWS.weight(w)
+        part = ShadowCache.split_part(K)
+        ld = 3 * part
+        xb = SCRATCH.zeroed_bf16(rows, ld, dev)                 # (padding columns K .. part of each block stay zero)
+        ops.cast_split3_bf16(x.contiguous(), d1, xb, ld, part, 2, rows, d1)
+        ops.cast_split3_bf16(gc.contiguous(), d2, xb, ld, part, 2, rows, d2, y_off=d1)
+        wb = SHADOWS.weight_split3(w)
         logp = torch.empty(B, L, V, device=dev)
-        ops.gemm(xb, wb, rows, V, K, lda=ld, ldb=wb.shape[1], C_f32=logp, ldc=V, bias=b.detach())
+        ops.gemm(xb, wb, rows, V, ld, lda=ld, ldb=ld, C_f32=logp, ldc=V, bias=b.detach())
         ops.log_softmax_(logp, V, rows, V)
         ctx.save_for_backward(xb, w, logp)
         ctx.cfg = (B, L, d1, d2, V)
@@ -1306,7 +1356,7 @@ class WorkerHeadFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         gb = SCRATCH.bf16(rows, V, dev)
         ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
-        wb = SHADOWS.weight(w)
+        wb = SHADOWS.weight_split3(w)                           # block 0 of both operands = the plain bf16 copies
         dcat = torch.empty(rows, K, device=dev) if (need[0] or need[1]) else None
         dw, db = _linear_bwd(gb, gb.shape[1], rows, V, xb, xb.shape[1], K, wb, need_dw=need[2], need_db=need[3],
                              need_dx=dcat is not None, dx_f32=dcat)

@@ -108,6 +108,14 @@ def attention_shared128_bwd(Qp, X, dCx, row_max, row_sum, delta, mask, mask_sb, 
                "bmhrl_attention_shared128_bwd")
 
 
+def softmax_bwd_rows(P, ldp, dP, lddp, dS, ldds, rows, cols, scale, mask=None, mask_sb=0, mask_sq=0, rows_per_query=1, queries=1):
+    """dS = scale * P * (dP - rowsum(P * dP)), 0 at masked keys; P bf16, dP fp32, dS bf16; rows = (sample, query, rows_per_query)"""
+    _need_cuda(P, dP, dS)
+    _lib.check(_lib.load().bmhrl_softmax_bwd_rows(P.data_ptr(), ldp, dP.data_ptr(), lddp, dS.data_ptr(), ldds, rows, cols, scale,
+                                                  _p(mask), mask_sb, mask_sq, rows_per_query, queries, stream()),
+               "bmhrl_softmax_bwd_rows")
+
+
 def softmax_rows(S, lds, P, ldp, rows, cols):
     _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr(), ldp, rows, cols, stream()), "bmhrl_softmax_rows")
 
@@ -158,6 +166,13 @@ def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_of
     _need_cuda(x, y)
     _lib.check(_lib.load().bmhrl_cast_bf16(x.data_ptr(), ldx, y.data_ptr() + 2 * y_off, ldy, rows, cols, scale, dropout_p,
                                            seed, _p(seed_dev), stream()), "bmhrl_cast_bf16")
+
+
+def cast_split3_bf16(x, ldx, y, ldy, part, lo_slot, rows, cols, y_off=0):
+    """y blocks [hi | . | .] of width `part`: bf16(x) in block 0, bf16(x - hi) in block lo_slot, hi again in the other"""
+    _need_cuda(x, y)
+    _lib.check(_lib.load().bmhrl_cast_split3_bf16(x.data_ptr(), ldx, y.data_ptr() + 2 * y_off, ldy, part, lo_slot, rows, cols,
+                                                  stream()), "bmhrl_cast_split3_bf16")
 
 
 def cast_colsum_bf16(x, ldx, y, ldy, rows, cols, colsum, scale=1.0, dropout_p=0.0, seed=0, seed_dev=None, colsum_off=0,

@@ -114,7 +114,7 @@ class FlatAdam:
                 if kind:
                     n, kk, ld = p.shape[0], p.shape[1], buf.shape[1]
                     if m:
-                        dst[id(p)] = (buf.data_ptr() + 2 * off * ld, n, kk, ld)
+                        dst[id(p)] = (buf.data_ptr() + 2 * off * ld, n, kk, ld | (SHADOWS.split.get(key, 0) << 32))
                     off += n
                 else:
                     if m:

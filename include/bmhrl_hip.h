@@ -128,6 +128,14 @@ int bmhrl_attention_config(int32_t head_dim, int32_t code);
 int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
                        bmhrl_stream_t stream);
 
+/* Backward of the same row softmax (autograd of F.softmax + masked_fill in attention(), model/multihead_attention.py:22-25):
+ * dS[r][c] = scale * P[r][c] * (dP[r][c] - sum_k P[r][k] dP[r][k]), 0 where the key is masked; P bf16 (rows, ldp), dP fp32
+ * (rows, lddp) -> dS bf16.  Rows are ordered (sample, query, rows_per_query) with `queries` queries per sample; mask (optional)
+ * is addressed mask[sample * mask_sb + query * mask_sq + c] (0 = masked). */
+int bmhrl_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lddp, void* dS, int64_t ldds,
+                           int64_t rows, int32_t cols, float scale, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                           int32_t rows_per_query, int32_t queries, bmhrl_stream_t stream);
+
 /* delta[b,h,q] = scale * sum_d dO[b,q,h,d] * O[b,q,h,d]   (softmax backward row term) */
 int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale,
                      int32_t B, int32_t H, int32_t Sq, int32_t DK, bmhrl_stream_t stream);
@@ -172,6 +180,13 @@ int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mix, const fl
  * and inverted dropout (regenerates the forward mask from seed: element id = row*cols + col). */
 int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, float scale,
                     float dropout_p, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
+
+/* Split operand of a GEMM that needs more than bf16's 8 mantissa bits (the vocabulary projection feeding log_softmax,
+ * model/bm_hrl_agent.py:463-466,483-484): hi = bf16(x), lo = bf16(x - hi); y gets three column blocks of width `part`:
+ * block 0 = hi, block lo_slot (1 or 2) = lo, the other block = hi.  Activations use lo_slot 2, weights lo_slot 1, so that one
+ * GEMM with K = 3 * part yields x_hi W_hi + x_hi W_lo + x_lo W_hi.  Padding columns (cols .. part) are not written. */
+int bmhrl_cast_split3_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part, int32_t lo_slot, int64_t rows,
+                           int32_t cols, bmhrl_stream_t stream);
 
 /* bmhrl_cast_bf16 + column sums of the rounded result in one pass: colsum[n] += sum_m y[m][n] (fp32 atomics; colsum is
  * accumulated into, the caller zeroes it).  dY cast and bias gradient of one layer -- nn.Linear's db of

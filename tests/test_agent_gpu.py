@@ -170,7 +170,10 @@ WATCH = ["bm_enc.encoder.layers.0.self_att_M1.linear_Q2d.weight", "bm_enc.encode
          "bm_enc.encoder.layers.0.feed_forward_M1.fc1.weight", "bm_enc.encoder.layers.1.res_layers_M2.1.norm.weight",
          "bm_worker_fus.decoder.layers.0.enc_att_V.linear_V2d.weight", "bm_manager_fus.decoder.layers.1.self_att.linear_Q2d.weight",
          "bm_worker_fus.decoder.layers.1.a_v_constant", "manager.linear.weight", "worker.goal_attention.linear_d2Q.weight",
-         "worker.core.projection.weight", "emb_C.embedder.weight"]
+         "worker.core.projection.weight", "emb_C.embedder.weight",
+         # score-path weights of the caption -> memory attentions (their gradient is what a cancellation leaves: see
+         # ops.softmax_bwd_rows)
+         "bm_worker_fus.decoder.layers.0.enc_att_A.linear_Q2d.weight", "bm_manager_fus.decoder.layers.1.enc_att_V.linear_K2d.weight"]
 
 
 def _forward_backward_vs_oracle(dev, B, Tv, Ta, n_layers, with_grads, extra_watch=()):
@@ -198,9 +201,8 @@ def _forward_backward_vs_oracle(dev, B, Tv, Ta, n_layers, with_grads, extra_watc
     assert np.array_equal(out[4].cpu().numpy(), ref[4].numpy())                    # int32 segment labels: exact
     errs = {"logp_maxnorm": rel(out[0], ref[0].detach()), "logp_elem_floor1": rel_elem(out[0], ref[0].detach())}
     assert errs["logp_maxnorm"] < 1e-3, errs
-    # per element, relative, |log-prob| floor 1.0 (the strict reading of north_star's 1e-3): measured 7.1e-4 (B=2) and 7.4e-4
-    # (B=16) at config 2 on MI355X; deeper stacks (N=6) and the long-segment shapes get the bound below
-    assert errs["logp_elem_floor1"] < (1e-3 if n_layers <= 2 and Ta <= 800 else 3e-3), errs
+    # per element, relative, |log-prob| floor 1.0 (the strict reading of north_star's 1e-3), every shape and depth
+    assert errs["logp_elem_floor1"] < 1e-3, errs
     assert rel(out[1], ref[1].detach()) < 1e-2 and rel(out[2], ref[2].detach()) < 1e-2 and rel(out[3], ref[3].detach()) < 1e-2
     if with_grads:
         loss = torch.sum(LabelSmoothing(0.7, 1)(out[0], trg_y.to(dev))) / (trg_y != 1).sum().to(dev)
@@ -213,12 +215,9 @@ def _forward_backward_vs_oracle(dev, B, Tv, Ta, n_layers, with_grads, extra_watc
         for k in watch:
             e = rel_l2(named[k].grad, sdr[k].grad)
             errs["grad:" + k] = e
-            # Score-path weights (Q2d / K2d) of the caption -> memory attentions: 30 queries over 256 / 800 keys with a
-            # near-uniform softmax at random init -- their gradient is the residual of a cancellation (rows of dS sum to
-            # zero, the memory rows share a large common component), 100x smaller in norm than the value-path gradients of
-            # the same block, and carries the bf16 rounding of P / dS at 6-13 % of its own norm (measured on MI355X, N=6).
-            score_path = ".enc_att_" in k and (k.endswith("linear_K2d.weight") or k.endswith("linear_Q2d.weight"))
-            assert e < (1.5e-1 if score_path else 2e-2), (k, e)
+            # first-layer weights <= 1e-2, every watched tensor <= 2e-2 (relative L2)
+            first_layer = k.startswith("bm_enc.encoder.layers.0.") and k.endswith(".weight") and ".norm." not in k
+            assert e < (1e-2 if first_layer else 2e-2), (k, e)
     print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in errs.items() if not k.startswith("grad:")},
           "worst grad rel-L2", max([v for k, v in errs.items() if k.startswith("grad:")] or [0.0]))
     return errs
@@ -435,8 +434,7 @@ def test_config3_worker_rl_step_full_width_vs_oracle(dev):
     for k in watch:
         e = rel_l2(named[k].grad, sdr[k].grad)
         worst = max(worst, e)
-        score_path = ".enc_att_" in k and (k.endswith("linear_K2d.weight") or k.endswith("linear_Q2d.weight"))
-        assert e < (1.5e-1 if score_path else 3e-2), (k, e)
+        assert e < 2e-2, (k, e)
     # value head: a 300 -> 600 -> 300 -> 1 MLP on bf16 operands; its masked-MSE gradient is a sum over 60 rows of residuals
     # (expected - target) that are themselves differences of O(1) numbers -- measured 1e-2 .. 6e-2 of the gradient's norm
     verr = {k: rel_l2(p.grad, vsdr[k].grad) for k, p in vnet.named_parameters()}

@@ -261,6 +261,65 @@ def test_softmax_rows_and_delta(dev):
     assert rel_err(delta, ref) < 1e-5
 
 
+def test_softmax_bwd_rows(dev):
+    """dS = scale * P * (dP - sum_k P dP) with the row term from the SAME rounded P, 0 at masked keys (masked_fill passes no
+    gradient): rows (sample, query, head), per-sample and per-query masks."""
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, L, H, Sk = 3, 5, 2, 37
+    Skp = 40
+    P = torch.zeros(B, L, H, Skp, dtype=torch.bfloat16)
+    P[..., :Sk] = bf(torch.softmax(torch.randn(B, L, H, Sk, generator=g) * 2, -1))
+    dP = torch.randn(B, L, H, Skp, generator=g) + 5.0          # a large common component: what the consistent row term cancels
+    for per_query in (False, True):
+        mask = torch.rand(B, L if per_query else 1, Sk, generator=g) < 0.8
+        mask[1] = False                                          # a fully masked sample: P is uniform there, dS must be 0
+        dS = torch.zeros(B, L, H, Skp, dtype=torch.bfloat16, device=dev)
+        m8 = mask.to(dev).contiguous()
+        ops.softmax_bwd_rows(P.to(dev), Skp, dP.to(dev), Skp, dS, Skp, B * L * H, Sk, 0.25, m8, m8.shape[1] * Sk,
+                             Sk if per_query else 0, H, L)
+        Pf, dPf = P[..., :Sk].double(), dP[..., :Sk].double()
+        ref = 0.25 * Pf * (dPf - (Pf * dPf).sum(-1, keepdim=True))
+        ref = ref * mask.unsqueeze(2).expand(B, L, H, Sk) if per_query else ref * mask.view(B, 1, 1, Sk)
+        assert rel_err(dS[..., :Sk].float(), ref) < 5e-3          # bf16 output rounding
+        assert float(dS[1].abs().max()) == 0.0 and float(dS[..., Sk:].abs().max()) == 0.0
+    dS = torch.zeros(B, L, H, Skp, dtype=torch.bfloat16, device=dev)
+    ops.softmax_bwd_rows(P.to(dev), Skp, dP.to(dev), Skp, dS, Skp, B * L * H, Sk, 1.0)
+    ref = Pf * (dPf - (Pf * dPf).sum(-1, keepdim=True))
+    assert rel_err(dS[..., :Sk].float(), ref) < 5e-3
+    # the rows of dS sum to ~0 although P is rounded (sum P != 1 is the only residue)
+    assert float(dS[..., :Sk].float().sum(-1).abs().max()) < 2e-2 * float(dS.float().abs().max())
+
+
+def test_split_operand_gemm(dev):
+    """[x_hi | x_hi | x_lo] x [W_hi | W_lo | W_hi]^T (ops.cast_split3_bf16, one GEMM with K = 3 part) reproduces the fp32
+    product to ~1e-5 where plain bf16 operands give ~3e-3 -- the vocabulary projection of WorkerHeadFn."""
+    from bmhrl_amd import ops
+    from bmhrl_amd.functional import ShadowCache
+    g = torch.Generator().manual_seed(8)
+    rows, K1, K2, N = 96, 300, 64, 1000
+    K = K1 + K2
+    x1, x2 = torch.randn(rows, K1, generator=g).to(dev), torch.randn(rows, K2, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    part = ShadowCache.split_part(K)
+    assert part == 384
+    xb = torch.zeros(rows, 3 * part, dtype=torch.bfloat16, device=dev)
+    wb = torch.zeros(N, 3 * part, dtype=torch.bfloat16, device=dev)
+    ops.cast_split3_bf16(x1, K1, xb, 3 * part, part, 2, rows, K1)
+    ops.cast_split3_bf16(x2, K2, xb, 3 * part, part, 2, rows, K2, y_off=K1)
+    ops.cast_split3_bf16(w, K, wb, 3 * part, part, 1, N, K)
+    x = torch.cat([x1, x2], -1)
+    hi = bf(x)
+    assert torch.equal(xb[:, :K], hi) and torch.equal(xb[:, part:part + K], hi)
+    assert torch.equal(xb[:, 2 * part:2 * part + K], bf(x - hi.float())) and float(xb[:, K:part].abs().max()) == 0.0
+    assert torch.equal(wb[:, part:part + K], bf(w - bf(w).float())) and torch.equal(wb[:, 2 * part:2 * part + K], bf(w))
+    y = torch.empty(rows, N, device=dev)
+    ops.gemm(xb, wb, rows, N, 3 * part, lda=3 * part, ldb=3 * part, C_f32=y, ldc=N)
+    ref = x.double() @ w.double().T
+    plain = bf(x).double() @ bf(w).double().T
+    assert rel_err(y, ref) < 3e-5 and rel_err(plain, ref) > 1e-3
+
+
 @pytest.mark.parametrize("rows,D", [(4096, 1024), (12800, 128), (480, 300), (33, 20), (1001, 128), (7, 64), (130, 96)])
 def test_layernorm(dev, rows, D):
     from bmhrl_amd import ops

@@ -189,6 +189,7 @@ def test_adam_pass_keeps_weight_shadows_current(setup):
             if fused:
                 mine = {id(p) for p in t.opt.params}
                 n_checked = 0
+                n_split = []
                 for store, is_w in ((SHADOWS.w, True), (SHADOWS.b, False)):
                     for key, (ver, buf, refs) in store.items():
                         params = [r() for r in refs]
@@ -198,13 +199,21 @@ def test_adam_pass_keeps_weight_shadows_current(setup):
                         off = 0
                         for p in params:                                       # ... and really is
                             if is_w:
-                                assert torch.equal(buf[off:off + p.shape[0], :p.shape[1]], p.detach().to(torch.bfloat16))
+                                hi = p.detach().to(torch.bfloat16)
+                                assert torch.equal(buf[off:off + p.shape[0], :p.shape[1]], hi)
+                                part = SHADOWS.split.get(key, 0)
+                                if part:          # [hi | lo | hi] shadow of the vocabulary projection (WorkerHeadFn)
+                                    n_split.append(key)
+                                    lo = (p.detach() - hi.float()).to(torch.bfloat16)
+                                    assert torch.equal(buf[:, part:part + p.shape[1]], lo)
+                                    assert torch.equal(buf[:, 2 * part:2 * part + p.shape[1]], hi)
+                                    assert float(buf[:, p.shape[1]:part].abs().max()) == 0.0      # padding stays zero
                                 off += p.shape[0]
                             else:
                                 assert torch.equal(buf[off:off + p.numel()], p.detach().reshape(-1))
                                 off += p.numel()
                             n_checked += 1
-                assert n_checked > 50
+                assert n_checked > 50 and len(n_split) == 1
         finally:
             FlatAdam.fused_shadows = True
     assert all(abs(a - c) <= 2e-3 * abs(c) for a, c in zip(losses[True], losses[False])), losses
