@@ -131,7 +131,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
       }
     }
     __syncthreads();
-    const uint8_t* __restrict__ Mk = (prob && p.mask) ? p.mask + b1 * p.mask_sb1 : nullptr;     // key mask (mask_sm == 0)
+    // key mask (mask_sm == 0).  PROB: masked scores are the -1e9 fill; DSCORE: the fill is a constant, so no gradient reaches
+    // the score of a masked key (masked_fill, model/multihead_attention.py:22 -- it only matters for a fully masked row,
+    // whose probabilities are uniform instead of zero)
+    const uint8_t* __restrict__ Mk = p.mask ? p.mask + b1 * p.mask_sb1 : nullptr;
     // a lane's 16 accumulator rows are 4 groups of 4 consecutive rows: the row vectors come in as 16-byte LDS reads, once
     // per 32-row tile (not once per element and output tile)
     auto finish = [&](const f32x16& av, const int mi, const int ni, const f32x4 (&r1)[4], const f32x4 (&r2)[4]) {
@@ -147,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
           const float x = keep ? av[r] * p.alpha : NEG_MASK;
           v = __expf(x - r1[r >> 2][r & 3]) * r2[r >> 2][r & 3];
         } else {
-          v = (float)*q * (av[r] - r1[r >> 2][r & 3]) * p.alpha;
+          v = keep ? (float)*q * (av[r] - r1[r >> 2][r & 3]) * p.alpha : 0.f;
         }
         *q = (bf16_t)v;
       }
@@ -226,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
       if (!keep) x = NEG_MASK;
       return __expf(x - rv) * rv2;
     } else if constexpr (KIND == 3) {
-      return aux * (x - rv) * p.alpha;
+      return keep ? aux * (x - rv) * p.alpha : 0.f;
     } else {
       return aux > 0.f ? x * p.alpha : 0.f;
     }
@@ -257,7 +260,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             x4[0] = (float)t[0]; x4[1] = (float)t[1]; x4[2] = (float)t[2]; x4[3] = (float)t[3];
           }
           uint32_t keep4 = 0x01010101u;        // mask bytes of the 4 columns (one 4-byte load when aligned)
-          if constexpr (decltype(kind)::value == 1 || decltype(kind)::value == 2) {
+          if constexpr (decltype(kind)::value == 1 || decltype(kind)::value == 2 || decltype(kind)::value == 3) {
             if (Mg) {
               const uint8_t* mp = Mg + (long)m * p.mask_sm + n;
               if (((uintptr_t)mp & 3) == 0) keep4 = *reinterpret_cast<const uint32_t*>(mp);
@@ -860,7 +863,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
                       d->ldcb % 8 == 0 && d->cb_sb1 % 8 == 0 && d->cb_sb2 % 8 == 0 && d->rowvec;
   a.fast_pd = (d->epilogue == BMHRL_EPI_PROB && out_ok && d->rowvec2 && (!d->mask || d->mask_sm == 0) && !d->aux) ||
               (d->epilogue == BMHRL_EPI_DSCORE && out_ok && d->aux && al(d->aux, 16) && d->ldaux % 8 == 0 &&
-               d->aux_sb1 % 8 == 0 && d->aux_sb2 % 8 == 0);
+               d->aux_sb1 % 8 == 0 && d->aux_sb2 % 8 == 0 && (!d->mask || d->mask_sm == 0));
   const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
   const long small_tiles = (long)((d->M + 63) / 64) * ((d->N + 63) / 64) * batch;
   // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight

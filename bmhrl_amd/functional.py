@@ -182,6 +182,18 @@ SEEDS = DropoutSeeds()
 
 
 # ------------------------------------------------------------------------------------------------ step-scoped scratch
+class ScratchState:
+    """What a StepScratch hands out, owned by whoever runs the steps (a CaptionTrainer): the fp32 arena, the bf16 pools and
+    their sizes.  A captured step bakes the ADDRESSES of these buffers into its graph, so they must live exactly as long as
+    their owner -- with one process-wide state, a second trainer that needed a larger arena freed the one a still-live graph
+    of the first trainer was reading (r02: module-global arena)."""
+
+    def __init__(self):
+        self.arena: Optional[torch.Tensor] = None
+        self.need = 0
+        self.pool = {}
+
+
 class StepScratch:
     """Zero-initialised scratch handed out inside ONE training step (between begin_step() and end_step(), as
     bmhrl_amd.train.CaptionTrainer does), so that a step issues one fill instead of ~250:
@@ -193,30 +205,39 @@ class StepScratch:
         the same order, every step.
 
     Outside a step (unit tests, inference) both fall back to freshly zeroed tensors.  The first step sizes the arena,
-    so everything is allocated before a HIP graph capture of the step (capture runs warm-up steps first)."""
+    so everything is allocated before a HIP graph capture of the step (capture runs warm-up steps first).  The buffers
+    themselves belong to the ScratchState passed to begin_step() (one per trainer); without one, a process-wide default."""
 
     def __init__(self):
         self.armed = False
-        self.arena: Optional[torch.Tensor] = None
+        self.state = self.default_state = ScratchState()
         self.off = 0
         self.spill = 0
-        self.need = 0
-        self.pool = {}
         self.cursor = {}
         self.memo = {}
 
-    def begin_step(self, device):
+    # (the buffers live in the bound state)
+    arena = property(lambda self: self.state.arena, lambda self, v: setattr(self.state, "arena", v))
+    need = property(lambda self: self.state.need, lambda self, v: setattr(self.state, "need", v))
+    pool = property(lambda self: self.state.pool)
+
+    def begin_step(self, device, state: Optional[ScratchState] = None):
         device = torch.device(device)
         if device.type != "cuda":
             return
+        self.state = state if state is not None else self.default_state
         if self.arena is None or self.arena.device != device or self.arena.numel() < self.need:
             self.arena = torch.zeros(self.need, device=device) if self.need else None
-        elif self.off:
-            self.arena[:self.off].zero_()
+        elif self.off_of_last_step():
+            self.arena[:self.off_of_last_step()].zero_()
         self.off = self.spill = 0
         self.cursor = {}
         self.memo = {}
         self.armed = True
+
+    def off_of_last_step(self) -> int:
+        """elements of the bound state's arena a step may have written (its own high-water mark)"""
+        return min(self.state.need, self.arena.numel()) if self.arena is not None else 0
 
     def end_step(self):
         self.need = max(self.need, self.off + self.spill)
@@ -358,7 +379,7 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     dS = _padded_bf16(B * H * Sq, Sk, dev).view(B, H, Sq, Skp)
     ops.gemm(dOb, Vb, Sq, Sk, dk, lda=D, ldb=ldv, b_off=v_off, batch=(B, H), a_strides=(Sq * D, dk),
              b_strides=(Sk * ldv, dk), C_bf16=dS, ldcb=Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale,
-             rowvec=delta, rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=pstr)
+             rowvec=delta, rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=pstr, mask=mask, mask_sb1=msb, mask_sm=msq)
     # dV = P^T dO ; dK = dS^T Q ; dQ = dS K
     ops.gemm(P, dOb, Sk, dk, Sq, lda=Skp, ldb=D, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,
              b_strides=(Sq * D, dk), C_bf16=dVb, ldcb=lddv, cb_off=dv_off, cb_strides=(Sk * lddv, dk), **csv)
@@ -707,7 +728,7 @@ class MemAttnFn(torch.autograd.Function):
                          mask=m8, mask_sb1=msb, mask_sm=0, rowvec=stats[0], rowvec2=stats[1], rv_strides=(H * L, L))
                 ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B, H), a_strides=(L * H * dmp, dmp),
                          b_strides=(Sk * dmp, 0), C_bf16=dS, ldcb=H * Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale,
-                         rowvec=delta, rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr)
+                         rowvec=delta, rv_strides=(H * L, L), aux=P, ldaux=H * Skp, aux_strides=pstr, mask=m8, mask_sb1=msb)
             else:
                 P = stats[0]
                 dP = torch.empty(B, L, H, Skp, device=dev)

@@ -494,11 +494,15 @@ class BMHrlAgent(nn.Module):
     # training: layer l of the worker and of the manager fusion stack run as ONE set of launches (functional.PairMemAttnFn)
     pair_fusion_stacks = os.environ.get("BMHRL_PAIR_STACKS", "1") == "1"
 
-    def _side_stream(self, device, attr="_critic_stream"):
-        st = getattr(self, attr, None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, attr, st)
+    _critic_streams = {}
+
+    def _side_stream(self, device):
+        """ONE critic stream per device for the whole process (like the layers' fork streams): torch hands streams out of a
+        pool of 32 per device, round robin -- a stream per agent would, after enough agents, be the very stream another fork
+        (or the graph capture itself) runs on."""
+        st = BMHrlAgent._critic_streams.get(device)
+        if st is None:
+            st = BMHrlAgent._critic_streams[device] = torch.cuda.Stream(device=device)
         return st
 
     def _segment_labels(self, emb):

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, synthetic as syn
-from .functional import SCRATCH, SEEDS, SHADOWS
+from .functional import SCRATCH, SEEDS, SHADOWS, ScratchState
 from .loss.biased_kl import BiasedKL
 from .loss.label_smoothing import LabelSmoothing
 from .model.bm_hrl_agent import BMHrlAgent, BMManagerValueFunction, BMWorkerValueFunction
@@ -340,6 +340,7 @@ class CaptionTrainer:
         for i, layer in enumerate(enc_layers):   # (V-stream, A-stream) after layer i: the cut between two backward phases
             layer.register_forward_hook(lambda mod, inp, out, i=i: self._layer_out.__setitem__(i, out))
         self.modality = "audio_video"
+        self.scratch = ScratchState()       # arena + operand pools of this trainer's steps: a captured step keeps their addresses
         self.graph = None
         self.static = None
         self.loss_weight = torch.ones((), device=self.device)   # token_weight() of the current batch (1 on one rank)
@@ -399,7 +400,7 @@ class CaptionTrainer:
         self.opt.zero_grad()
         if self.value_net is not None:
             self.vopt.zero_grad()
-        SCRATCH.begin_step(self.device)
+        SCRATCH.begin_step(self.device, self.scratch)
         SEEDS.dev.add_(1)
         SHADOWS.refresh()
         loss, _ = self._forward_loss(fs, trg_in, trg_y, rl)
@@ -416,6 +417,8 @@ class CaptionTrainer:
         return loss.detach()
 
     # ------------------------------------------------------------------ whole-step HIP graph
+    _warm_streams = {}
+
     def capture(self, fs, captions, warmup: int = 3):
         """Capture step() for static shapes; afterwards replay(fs, captions) copies the inputs into the captured
         buffers and launches the graph.  The all-reduce stays outside the graph (between two captured halves) when
@@ -423,7 +426,9 @@ class CaptionTrainer:
         self.static = {k: v.clone() for k, v in fs.items()}
         self.static["captions"] = captions.clone()
         self.static_loss = torch.zeros((), device=self.device)
-        s = torch.cuda.Stream()
+        s = CaptionTrainer._warm_streams.get(self.device)      # one warm-up stream per device and process (the pool of 32 wraps)
+        if s is None:
+            s = CaptionTrainer._warm_streams[self.device] = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
@@ -483,7 +488,7 @@ class CaptionTrainer:
         self.opt.zero_grad()
         if self.value_net is not None:
             self.vopt.zero_grad()
-        SCRATCH.begin_step(self.device)
+        SCRATCH.begin_step(self.device, self.scratch)
         SEEDS.dev.add_(1)
         if not self.opt.fused_shadows:
             SHADOWS.invalidate()

@@ -36,7 +36,7 @@ typedef void* bmhrl_stream_t; /* hipStream_t */
 enum {
   BMHRL_EPI_LINEAR = 0, /* v = alpha*acc (+bias[n]) ; mask==0 -> -1e9 ; relu ; dropout ; (+residual[m][n]) */
   BMHRL_EPI_PROB = 1,   /* p = exp(masked(alpha*acc) - rowvec[m]) / rowvec2[m]        (recompute softmax P) */
-  BMHRL_EPI_DSCORE = 2, /* ds = aux[m][n] * (acc - rowvec[m]) * alpha               (softmax backward)     */
+  BMHRL_EPI_DSCORE = 2, /* ds = aux[m][n] * (acc - rowvec[m]) * alpha, 0 where mask == 0 (softmax backward) */
   BMHRL_EPI_RELU_BWD = 3 /* dz = aux[m][n] > 0 ? alpha*acc : 0     (ReLU + inverted-dropout backward of the FFN) */
 };
 

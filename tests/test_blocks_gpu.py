@@ -193,9 +193,12 @@ def test_linear_layernorm_gate_workerhead(dev):
     got = [t.grad.clone() for t in (x, gc, wp, bp)]
     for t in (x, gc, wp, bp):
         t.grad = None
+    # forward: split (hi + lo) bf16 operands -> the fp32 product to ~1e-5; backward: the hi parts only (plain bf16 operands)
+    exact = torch.log_softmax(F.linear(torch.cat([x, gc], -1).double(), wp.double(), bp.double()), -1)
+    assert rel(lp, exact.float()) < 2e-5
     ref = torch.log_softmax(F.linear(torch.cat([bfr(x), bfr(gc)], -1), bfr(wp), bp), -1)
     ref.backward(dlp)
-    assert rel(lp, ref) < 1e-4
+    assert rel(lp, ref) > 1e-4          # (plain bf16 operands are measurably off: that is what the split buys)
     for aa, t in zip(got, (x, gc, wp, bp)):
         assert rel(aa, t.grad) < 1e-2
 

@@ -120,6 +120,26 @@ def test_gemm_batched_attention_epilogues(dev):
              rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=(H * Sq * Skp, Sq * Skp))
     dS_ref = Pb * (doh @ vh.transpose(-1, -2) - delta[..., None]) * scale
     assert rel_err(dS[..., :Sk].float(), dS_ref) < 1e-2
+    # with the key mask: the -1e9 fill is a constant (masked_fill), so a masked key's score gets NO gradient -- also in a fully
+    # masked row, where P is uniform instead of zero (torch autograd of the reference's op chain is the check)
+    mask2 = mask.clone()
+    mask2[1, :] = 0
+    sq = ((qh @ kh.transpose(-1, -2)) * scale).requires_grad_(True)
+    p2 = torch.softmax(sq.masked_fill(mask2.view(B, 1, 1, Sk) == 0, -1e9), -1)
+    (p2 @ vh).backward(doh)
+    P2 = torch.zeros_like(P)
+    P2[..., :Sk] = bf(p2.detach())
+    delta2 = (doh * (P2[..., :Sk].float() @ vh)).sum(-1).contiguous()
+    for fast in (True, False):                           # 16-byte epilogue and the generic one (odd leading dimension of aux)
+        ldp = Skp if fast else Skp + 4
+        Pin = torch.zeros(B, H, Sq, ldp, dtype=torch.bfloat16, device=dev)
+        Pin[..., :Sk] = P2[..., :Sk]
+        dS2 = torch.zeros_like(P)
+        ops.gemm(dO, V, Sq, Sk, dk, lda=D, ldb=D, batch=(B, H), a_strides=(Sq * D, dk), b_strides=(Sk * D, dk), C_bf16=dS2,
+                 ldcb=Skp, cb_strides=(H * Sq * Skp, Sq * Skp), epilogue=ops.EPI_DSCORE, alpha=scale, rowvec=delta2,
+                 rv_strides=(H * Sq, Sq), aux=Pin, ldaux=ldp, aux_strides=(H * Sq * ldp, Sq * ldp), mask=mask2, mask_sb1=Sk, mask_sm=0)
+        assert float(dS2[1].abs().max()) == 0.0 and float(sq.grad[1].abs().max()) == 0.0
+        assert rel_err(dS2[..., :Sk].float(), sq.grad * scale) < 1.5e-2       # (dS is taken w.r.t. the unscaled product)
     # dV = P^T dO  (both operands transposed: reduction runs over rows of P and dO)
     dV = torch.empty(B, Sk, D, device=dev)
     ops.gemm(P, dO, Sk, dk, Sq, lda=Skp, ldb=D, a_trans=True, b_trans=True, batch=(B, H),
