@@ -4,7 +4,8 @@
 A step = one warmstart training step of the bimodal transformer (forward, label-smoothing KL loss, backward,
 gradient all-reduce when N > 1, Adam) on one synthetic batch B=16 per GPU, Tv=256, Ta=800, L=30, V=10172, N=2 layers,
 d_model=1024, H=4, dropout 0.1 in train mode (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed
-region.  One process per GPU; for N > 1 launch with torch.distributed.run (RCCL all-reduce of the flat gradient bucket).
+region.  One process per GPU (RCCL all-reduce of the flat gradient bucket): for N > 1 launch with torch.distributed.run, or
+just `python bench.py --gpus N` -- without WORLD_SIZE in the environment the script starts its N ranks itself.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     -- the cross-modal attention kernels (V<-A: B16 H4 Sq256 Sk800; A<-V: Sq800 Sk256) with the step's padded
@@ -233,8 +234,29 @@ def cpu_baseline(args):
                       f"linearly to B={args.batch}"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher (the reference needs none either: nn.DataParallel,
+    scripts/train_rl_captioning_module.py:95-99): start the N ranks as children under torch.distributed.run -- before this
+    process touches the GPU -- and leave with their exit code.  The JSON line is rank 0's."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
+    if n_dev < args.gpus and os.environ.get("BMHRL_BENCH_ONE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible -- refusing to report a smaller job as {args.gpus} GPUs")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] WORLD_SIZE unset: starting {args.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -256,7 +278,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     from bmhrl_amd import _lib, synthetic as syn
     from bmhrl_amd.train import CaptionTrainer

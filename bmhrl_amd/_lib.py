@@ -78,7 +78,7 @@ PROTOTYPES = {
     "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
     "bmhrl_log_softmax_bwd": [ptr, ptr, i64, ptr, i64, i64, i32, ptr],
     "bmhrl_smooth_kl_amp_grad": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i64, i32, ptr],
-    "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr, ptr],
+    "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr, i64, ptr],
     "bmhrl_reinforce_fwd": [ptr, i64, i32, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_reinforce_bwd": [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_gemm_f32": [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, ptr],
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
     lib.bmhrl_layernorm_bwd_workspace.restype = C.c_int64
     lib.bmhrl_attention_shared128_bwd_workspace.argtypes = [i32, i32, i32]
     lib.bmhrl_attention_shared128_bwd_workspace.restype = C.c_int64
+    lib.bmhrl_attention_max_keys.restype = C.c_int
     lib.bmhrl_hip_arch.restype = C.c_char_p
     lib.bmhrl_hip_abi_version.restype = C.c_int
     _lib = lib

@@ -85,6 +85,8 @@ int g_cfg256 = 0;   // (QW, KW) split: 0 = automatic; bmhrl_attention_config() p
 
 }  // namespace
 
+extern "C" int bmhrl_attention_max_keys(void) { return AttnCfg<256, 4, 1, 3, false>::MAX_SK; }
+
 extern "C" int bmhrl_attention_config(int32_t head_dim, int32_t code) {
   // code = 10 * QW + KW (41 or 22), 0 = the automatic choice
   if (head_dim == 256) g_cfg256 = code;

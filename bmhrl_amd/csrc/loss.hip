@@ -231,7 +231,7 @@ __global__ void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const fl
 
 // Inverse-CDF categorical sample with one uniform per row (or arg-max), block per row.
 __global__ void sample_kernel(const float* __restrict__ logp, long ld, int64_t* __restrict__ out, float* __restrict__ p_out,
-                              int V, int greedy, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+                              int V, int greedy, uint64_t seed, const uint64_t* __restrict__ seed_dev, long row_offset) {
   if (seed_dev) seed += seed_dev[0];          // a device word advanced per step: fresh samples under graph replay
   __shared__ float part[256];
   __shared__ int best_i[256];
@@ -263,7 +263,7 @@ __global__ void sample_kernel(const float* __restrict__ logp, long ld, int64_t* 
   if (tid == 0) {
     float total = 0.f;
     for (int i = 0; i < nt; ++i) total += part[i];
-    const float u = uniform01(seed, (uint64_t)row) * total;
+    const float u = uniform01(seed, (uint64_t)(row + row_offset)) * total;   // (row_offset: this rank's first row of the global batch)
     float acc = 0.f;
     int t = 0;
     while (t < nt - 1 && acc + part[t] <= u) acc += part[t++];
@@ -378,10 +378,11 @@ extern "C" int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int6
 }
 
 extern "C" int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
-                                   int32_t greedy, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream) {
-  BMHRL_CHECK_ARG(logp && out && rows > 0 && V > 0);
+                                   int32_t greedy, uint64_t seed, const uint64_t* seed_dev, int64_t row_offset,
+                                   bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && out && rows > 0 && V > 0 && row_offset >= 0);
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, out, p_out, V, greedy, seed,
-                     seed_dev);
+                     seed_dev, (long)row_offset);
   return hip_status(hipGetLastError());
 }
 

@@ -84,19 +84,20 @@ def get_norm_reward_factor(train_worker, mask, segments):
     return (mask if train_worker else segments).sum(dim=-1).reshape(-1, 1)
 
 
-def sample_actions(prediction, greedy, seed, seed_dev=None):
+def sample_actions(prediction, greedy, seed, seed_dev=None, row_offset=0):
     """a ~ Categorical(exp(prediction)) (worker) or arg-max (manager), and p(a) -- one kernel, no host sync (:283-286).
-    seed_dev: optional device word added to the seed (a captured step draws fresh samples at every replay)."""
+    seed_dev: optional device word added to the seed (a captured step draws fresh samples at every replay); row_offset: first
+    row of this rank's share of the global batch (the uniform of a row is a function of (seed, global row))."""
     from .. import ops
     B, L, V = prediction.shape
     out = torch.empty(B, L, dtype=torch.int64, device=prediction.device)
     p = torch.empty(B, L, device=prediction.device)
-    ops.sample_tokens(prediction.detach().contiguous(), V, out, p, B * L, V, greedy, seed, seed_dev)
+    ops.sample_tokens(prediction.detach().contiguous(), V, out, p, B * L, V, greedy, seed, seed_dev, row_offset)
     return out, p
 
 
 def biased_kl(train_worker, prediction, scorer, expected_scores, trg, trg_caption, mask, segments, device, biased_kldiv,
-              stabilize, reward_fn=None, seed=None, seed_dev=None):
+              stabilize, reward_fn=None, seed=None, seed_dev=None, row_offset=0):
     """The reference's biased_kl (:271-334), both branches.  Worker: a ~ Categorical(exp(prediction)), amplitude =
     clamp(score * p(a) * n_tokens_row, 0, 1).  Manager (:299-317): a = arg-max, score *= segments, amplitude =
     clamp(score * prod_{segment} p(a) * n_segments_row, 0, 1) and the expected scores are summed per segment, with the
@@ -105,7 +106,7 @@ def biased_kl(train_worker, prediction, scorer, expected_scores, trg, trg_captio
     config 3: synthetic), else the scorer's delta_*_worker / delta_*_manager."""
     from .. import rl_glue
     seed = random.getrandbits(62) if seed is None else seed
-    sampled, _ = sample_actions(prediction, greedy=not train_worker, seed=seed, seed_dev=seed_dev)
+    sampled, _ = sample_actions(prediction, greedy=not train_worker, seed=seed, seed_dev=seed_dev, row_offset=row_offset)
     if reward_fn is not None:
         score = reward_fn(sampled, trg_caption)
     elif train_worker:

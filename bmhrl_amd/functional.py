@@ -315,8 +315,10 @@ def _mask_u8(mask: Optional[torch.Tensor]):
 
 
 # ------------------------------------------------------------------------------------------------ attention core
-def _use_flash(dk: int, Sq: int) -> bool:
-    return dk == 256 and Sq >= 128
+def _use_flash(dk: int, Sq: int, Sk: int) -> bool:
+    """fused kernel: head dimension 256, enough queries to fill it, and a memory within the kernels' key limit (longer
+    ones take the materialised GEMM path)"""
+    return dk == 256 and Sq >= 128 and Sk <= ops.attention_max_keys()
 
 
 def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, msq, B, H, Sq, Sk, dk, p_drop, seed):
@@ -326,7 +328,7 @@ def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, ms
     D = H * dk
     scale = 1.0 / math.sqrt(dk)
     O = torch.empty(B * Sq, D, dtype=_BF16, device=dev)
-    if _use_flash(dk, Sq):
+    if _use_flash(dk, Sq, Sk):
         rmax = torch.empty(B, H, Sq, device=dev)
         rsum = torch.empty(B, H, Sq, device=dev)
         ops.attention_fwd(Qb, Kb, Vb, O, rmax, rsum, mask, msb, msq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, D,
@@ -635,7 +637,7 @@ class MemAttnFn(torch.autograd.Function):
                  b_strides=(0, dk * w_k.shape[1]), C_bf16=Qp, ldcb=H * dmp, cb_strides=(0, dmp))
         m8, msb, msq = _mask_u8(mask)
         Cx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
-        flash = dm == 128 and L >= 128 and msq == 0
+        flash = dm == 128 and L >= 128 and msq == 0 and Sk <= ops.attention_max_keys()
         if flash:
             # many queries against the 128-wide (audio) rows: fused kernel, one key / value tile for all heads; the
             # probabilities are recomputed in backward from the softmax statistics

@@ -12,6 +12,11 @@ from . import _lib
 EPI_LINEAR, EPI_PROB, EPI_DSCORE, EPI_RELU_BWD = 0, 1, 2, 3
 
 
+def attention_max_keys() -> int:
+    """largest Sk of the fused attention kernels (bmhrl_attention_max_keys)"""
+    return _lib.load().bmhrl_attention_max_keys()
+
+
 def pad8(n: int) -> int:
     return (n + 7) & ~7
 
@@ -256,9 +261,9 @@ def log_softmax_bwd(dlogp, logp, ld, g_bf16, ldg, rows, V):
                "bmhrl_log_softmax_bwd")
 
 
-def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed, seed_dev=None):
+def sample_tokens(logp, ld, out, p_out, rows, V, greedy, seed, seed_dev=None, row_offset=0):
     _lib.check(_lib.load().bmhrl_sample_tokens(logp.data_ptr(), ld, out.data_ptr(), _p(p_out), rows, V, int(greedy), seed,
-                                               _p(seed_dev), stream()), "bmhrl_sample_tokens")
+                                               _p(seed_dev), row_offset, stream()), "bmhrl_sample_tokens")
 
 
 def reinforce_fwd(pred, ld, action, value, critic_value, row_policy, row_value, rows, V, is_logp=True):

@@ -97,6 +97,11 @@ class FlatAdam:
         sig = tuple((kind, key, buf.data_ptr()) for kind, key, buf, _, _ in groups)
         gptrs = self.__dict__.get("_direct_ptrs")
         cached = self.__dict__.get("_seg_plan")
+        if gptrs is not None and self.__dict__.get("_grad_dirty", True) and not torch.cuda.is_current_stream_capturing():
+            # the direct path reads the bucket only for parameters without a gradient: they must find zeros there, also when
+            # a cached plan is reused after a step that went through the gather path (which leaves gradients in the bucket)
+            self.grad.zero_()
+            self._grad_dirty = False
         if cached is not None and cached[0] == sig and cached[2] == gptrs:
             return cached[1]
         if torch.cuda.is_current_stream_capturing():
@@ -121,9 +126,6 @@ class FlatAdam:
                         dst[id(p)] = (buf.data_ptr() + 4 * off, 1, p.numel(), 0)
                     off += p.numel()
         rows, blk = [], 0
-        if gptrs is not None and self.__dict__.get("_grad_dirty", True):
-            self.grad.zero_()              # parameters without a gradient read zeros from the bucket (nothing else writes it now)
-            self._grad_dirty = False
         for i, (p, o, sz) in enumerate(zip(self.params, self.offsets, self.sizes)):
             d = dst.get(id(p), (0, 1, sz, 0))
             rows.append([o, d[0], d[1], d[2], d[3], blk, gptrs[i] if gptrs is not None else 0])
@@ -206,8 +208,9 @@ class FlatAdam:
             return 1.0 / dist.get_world_size(group)
         return 1.0
 
-    def all_reduce_part(self, part: int, group=None):
-        """asynchronous all-reduce (sum) of one bucket; returns the work handle (None without a group)"""
+    def all_reduce_part(self, part: Optional[int], group=None):
+        """asynchronous all-reduce (sum) of one bucket (None: the whole flat gradient); returns the work handle (None without
+        a group)"""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             plo, phi = self._bucket_range(part)
             lo, hi = self._elem_off(plo), self._elem_off(phi)
@@ -367,7 +370,7 @@ class CaptionTrainer:
             n_row = loss_mask.sum(-1, keepdim=True).expand_as(trg_y).float()
             rows, _ = self.rl_criterion.biased_kl_from_score(pred, trg_y, sampled, score, n_row)
             loss = torch.sum(rows) / (n_tokens * (4.0 / 20.0))
-        if self._world_scale() != 1.0:
+        if self._world_scale() != 1.0 and self.phase == "warmstart":
             loss = loss * self.loss_weight       # global n_tokens normalisation (token_weight); a device scalar: graph-safe
         return loss, pred
 
@@ -379,9 +382,16 @@ class CaptionTrainer:
         from .epoch_loops.captioning_bmrl_loops import biased_kl
         worker = self.phase == "worker"
         expected = (self.value_net((w_feat.detach(), goals.detach())) if worker else self.value_net(m_feat.detach())).squeeze(-1)
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         rows, scores, _, _ = biased_kl(worker, pred, None, expected.detach(), trg_y, None, loss_mask, seg, pred.device,
-                                       self.rl_criterion, self.stabilize, reward_fn=self.reward_fn, seed=12345, seed_dev=SEEDS.dev)
+                                       self.rl_criterion, self.stabilize, reward_fn=self.reward_fn, seed=12345, seed_dev=SEEDS.dev,
+                                       row_offset=rank * trg_y.numel())       # ranks draw independent samples
         cap_loss = torch.sum(rows) / (n_tokens * (4.0 / 20.0))
+        if self._world_scale() != 1.0:
+            # more than one rank: only the captioning term is normalised by a token count (token_weight makes the averaged
+            # gradient that of the gathered batch); the value loss is a plain mean over B x L (reference :871-873) -- ranks
+            # hold equal B, so the average of the ranks' means IS the gathered mean and it must not be re-weighted
+            cap_loss = cap_loss * self.loss_weight
         vmask = loss_mask.float() if worker else seg.detach().float()
         value_loss = (((expected - scores[0].float()) ** 2) * vmask).mean()
         self.last_value_loss = value_loss.detach()
@@ -472,8 +482,6 @@ class CaptionTrainer:
         return 1.0 / dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1.0
 
     def _split(self) -> bool:
-        if self.phase != "warmstart":
-            return False                          # (the RL phases take the one-phase backward + one all-reduce per bucket)
         if self.split_backward is None:
             import os
             if os.environ.get("BMHRL_SPLIT_BACKWARD") in ("0", "1"):      # tuning / rehearsal override
@@ -499,12 +507,18 @@ class CaptionTrainer:
         loss, _ = self._forward_loss(st, trg_in, trg_y)
         if self._split():
             # phase 0 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)
-            cut = list(self._layer_out[self.n_enc - 1])
-            outs = torch.autograd.grad(loss, self.early_params + cut, retain_graph=True, allow_unused=True)
-            for p, g in zip(self.early_params, outs):
+            # (RL phases: the value head hangs off detached features -- its parameters are leaves of this first phase too; in
+            # the manager phase the encoder is frozen and the cut carries no gradient: the later phases then have nothing to do)
+            cut = [t for t in self._layer_out[self.n_enc - 1] if t.requires_grad]
+            vparams = list(self.vopt.params) if self.value_net is not None else []
+            leaves = self.early_params + vparams
+            outs = torch.autograd.grad(loss, leaves + cut, retain_graph=bool(cut), allow_unused=True)
+            for p, g in zip(leaves, outs):
                 p.grad = g
-            self._cut = (cut, list(outs[len(self.early_params):]))
+            self._cut = (cut, list(outs[len(leaves):]))
             self.opt.gather_grads(0)
+            if self.value_net is not None:
+                self.vopt.gather_grads()
         else:
             loss.backward()
             self.opt.gather_grads()
@@ -521,8 +535,11 @@ class CaptionTrainer:
         pairs = [(t, g) for t, g in zip(cut, gcut) if g is not None]
         params = self.phase_params[j]
         below = list(self._layer_out[idx - 1]) if idx > 0 else []
-        outs = torch.autograd.grad([t for t, _ in pairs], params + below, grad_outputs=[g for _, g in pairs],
-                                   retain_graph=idx > 0, allow_unused=True)
+        if pairs and params:
+            outs = torch.autograd.grad([t for t, _ in pairs], params + below, grad_outputs=[g for _, g in pairs],
+                                       retain_graph=idx > 0, allow_unused=True)
+        else:                                     # frozen encoder (manager phase): nothing flows below the cut
+            outs = [None] * (len(params) + len(below))
         for p, g in zip(params, outs):
             p.grad = g
         self._cut = (below, list(outs[len(params):])) if idx > 0 else None
@@ -550,6 +567,8 @@ class CaptionTrainer:
             return self.static_loss
         if self._split():
             works = [self.opt.all_reduce_part(0)]             # overlaps the encoder backward below
+            if self.value_net is not None:
+                works.append(self.vopt.all_reduce_part(None))
             for j, g in enumerate(self.graph_a2, start=1):
                 g.replay()
                 works.append(self.opt.all_reduce_part(j))     # layer by layer: only the first layer's bucket is exposed

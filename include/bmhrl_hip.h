@@ -119,6 +119,10 @@ int bmhrl_attention_shared128_bwd(const void* Qp, int64_t ldq, const void* X, in
                                   float* workspace, int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale,
                                   bmhrl_stream_t stream);
 
+/* Largest Sk the fused attention kernels accept (their key-mask ballots live in LDS); longer memories take the materialised
+ * GEMM path of the host code. */
+int bmhrl_attention_max_keys(void);
+
 /* Tuning aid: pin the (query blocks x key splits) shape of the attention workgroups -- head_dim 256 or 128; code = 10 * QW + KW
  * (41: 4 x 1, 22: 2 x 2), 0 = automatic (the default).  Process-wide, not thread-safe; results do not depend on it. */
 int bmhrl_attention_config(int32_t head_dim, int32_t code);
@@ -256,10 +260,11 @@ int bmhrl_smooth_kl_amp_grad(const float* logp, int64_t ld, const int64_t* trg, 
                              const float* n_row, float smoothing, int32_t pad_idx, int32_t zero_pad_rows, float* out,
                              int64_t rows, int32_t V, bmhrl_stream_t stream);
 /* a ~ Categorical(exp(logp)) by inverse CDF with one uniform per row (counter RNG: seed (+ *seed_dev when given: a device
- * word advanced per step, so that a captured step draws fresh samples at every replay), row);
+ * word advanced per step, so that a captured step draws fresh samples at every replay), row_offset + row -- row_offset = the
+ * first row of this rank's share of the global batch, so that data-parallel ranks draw independent samples);
  * greedy != 0 -> argmax.  epoch_loops/captioning_bmrl_loops.py:283-284 */
 int bmhrl_sample_tokens(const float* logp, int64_t ld, int64_t* out, float* p_out, int64_t rows, int32_t V,
-                        int32_t greedy, uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
+                        int32_t greedy, uint64_t seed, const uint64_t* seed_dev, int64_t row_offset, bmhrl_stream_t stream);
 /* Reinforce (loss/biased_kl.py:69-81): per-row terms of -adv*log(clamp(p(a), 1e-5, 1-1e-5)) and adv^2, adv = value -
  * critic_value; `pred` holds log-probs (is_logp = 1) or probabilities (0, the reference's input).  The backward
  * writes d(gscale * (mean(policy) + mean(value terms))) w.r.t. the (rows, V) probabilities, value and critic_value. */

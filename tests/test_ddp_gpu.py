@@ -34,6 +34,11 @@ def _batch(seeds, dev):
     return {k: torch.cat([p[k] for p in parts]).to(dev) for k in ("rgb", "flow", "audio", "captions")}
 
 
+def _reward(sampled, captions):
+    """deterministic stand-in for the scorer (BASELINE configs[2] stubs the rewards): a function of the drawn tokens only"""
+    return (sampled % 17).float() / 17.0
+
+
 def _run(tr, b):
     fs = {k: b[k] for k in ("rgb", "flow", "audio")}
     tr.capture(fs, b["captions"], warmup=1)          # one real (eager-bodied) step, then the captured one
@@ -84,3 +89,47 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     assert err <= 3e-2, err                                                   # bf16 operands, different tile paths for B=2 / B=4
     upd = float((flat0 - tr.opt.flat.cpu()).abs().max())
     assert upd <= 2.5e-4, upd                                                 # two Adam steps of lr 1e-4: at most 2e-4 apart
+
+
+def _rl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmhrl_amd.train import CaptionTrainer
+    dev = torch.device("cuda:0")
+    tr = CaptionTrainer(_cfg(), V, dev, seed=0, phase="worker", reward_fn=_reward)
+    assert tr._split()                               # the RL phases take the phased backward too
+    b = _batch([40 + rank], dev)
+    loss = _run(tr, b)
+    out[rank] = (tr.opt.flat.cpu(), (tr.opt.grad / world).cpu(), (tr.vopt.grad / world).cpu(), tr.vopt.flat.cpu(), loss,
+                 float(tr.last_value_loss))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_worker_rl_phase_equal_one_process():
+    """phase="worker" (train_bimodal_bl: sampled tokens, biased KL / (n_tokens 4/20) + the value head's masked MSE): two ranks ==
+    one process on the concatenated batch, for BOTH optimisers.  The captioning term carries the token weight, the value loss
+    (a plain mean over B x L) does not; rank r draws the uniforms of the global rows r B L ... (bmhrl_sample_tokens row_offset)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_rl_worker, args=(world, port, out), nprocs=world, join=True)
+    flat0, grad0, vgrad0, vflat0, loss0, vl0 = out[0]
+    flat1, grad1, vgrad1, vflat1, loss1, vl1 = out[1]
+    assert torch.equal(flat0, flat1) and torch.equal(grad0, grad1) and torch.equal(vgrad0, vgrad1) and torch.equal(vflat0, vflat1)
+
+    from bmhrl_amd.train import CaptionTrainer
+    dev = torch.device("cuda:0")
+    tr = CaptionTrainer(_cfg(), V, dev, seed=0, phase="worker", reward_fn=_reward)
+    tr.split_backward = False
+    tr.opt.direct_grads = tr.vopt.direct_grads = False
+    b = _batch([40, 41], dev)
+    _run(tr, b)
+    ref_grad, ref_vgrad = tr.opt.grad.cpu(), tr.vopt.grad.cpu()
+    assert abs(float(tr.last_value_loss) - 0.5 * (vl0 + vl1)) <= 2e-2 * abs(float(tr.last_value_loss))
+    err = float((grad0 - ref_grad).norm() / ref_grad.norm())
+    verr = float((vgrad0 - ref_vgrad).norm() / ref_vgrad.norm())
+    assert err <= 3e-2 and verr <= 5e-2, (err, verr)
+    assert float((flat0 - tr.opt.flat.cpu()).abs().max()) <= 2.5e-4 and float((vflat0 - tr.vopt.flat.cpu()).abs().max()) <= 2.5e-4
