@@ -441,6 +441,17 @@ class CaptionTrainer:
             s = CaptionTrainer._warm_streams[self.device] = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
+            if self.scratch.arena is None:
+                # size this trainer's scratch arena first: a pass without the optimizer (weights untouched).  The warm-up
+                # steps below then already work on the arena slices the captured step will use -- the Adam pass reads the
+                # gradients where autograd leaves them, and its table holds those addresses
+                self._sync_token_weight(self.static["captions"])
+                self._graph_body_a()
+                if self._split():
+                    for j in range(1, self.n_enc + 1):
+                        self._graph_body_phase(j)
+                self.opt.zero_grad()
+                SEEDS.dev.sub_(1)             # (the pass does not count as a step: dropout masks / samples continue as if it had not run)
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._sync_token_weight(self.static["captions"])
                 self._graph_body_a()
