@@ -145,6 +145,12 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   using C = AttnCfg<DK, QW, KW, NS, SHARED>;
   constexpr int NW = C::NW, NT = C::NT, BN = C::BN, VST = C::VST, ND = C::ND, NH = C::NH;
   constexpr int NQ = DK / 16;                  // MFMAs of one S^T chain (= of the O^T update of one tile)
+  // LDS layout of the operand stages.  Default: [stage][BN rows].  The scheduled head-dimension-128 loop addresses every
+  // stage through the 16-bit immediate of the DS instructions, so a wave's rows of all stages must lie within 64 KiB of its
+  // base register: [key split][stage][32 rows] -- a split's NS stages are contiguous (NS * 8 KiB).
+  constexpr bool SCHED128 = DK == 128 && PF && SHARED;
+  constexpr int STG = SCHED128 ? 32 * DK : VST;          // elements from a stage to the next (as seen by one key split)
+  constexpr int KSB = SCHED128 ? NS * 32 * DK : 32 * DK; // elements from a key split's rows to the next split's
   // head dimension 256 needs both halves of the 512-register file (one wave per SIMD): Q^T and O^T in the accumulator
   // half.  Head dimension 128 (256 registers, two waves per SIMD) is built with the VGPR form of the MFMAs and no
   // accumulator-register operand at all (attention128.hip).
@@ -209,6 +215,8 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   constexpr int GLT = (SHARED ? 1 : 2) * GL;           // pieces per wave and iteration
   const int hi = lane / CPR, pch = lane % CPR;
   const int wrow = wave_s * RW;
+  static_assert(!SCHED128 || (32 % RW == 0), "a wave's staged rows stay inside one key split");
+  const int wdst = SCHED128 ? (wrow / 32) * KSB + (wrow % 32) * DK : wrow * DK;      // element offset of the wave's first row in a stage
   auto swz_k = [](int row) { return SHARED ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & 15); };
   auto swz_v = [](int row) { return SHARED ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row & 3) << 2); };
   // Addressing: every load of an operand tile uses ONE uniform base (tile row k0 + RW w, in SGPRs) plus a per-lane
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
     }
   };
   // stage s of K at smem + s * VST, of V at smem + (NS + s) * VST; the shared image has the K stages only
-  auto issue_k = [&](int t) { issue_tile(Kgb, p.ldk, koffb, true, t, smem + (t % NS) * VST + wrow * DK); };
+  auto issue_k = [&](int t) { issue_tile(Kgb, p.ldk, koffb, true, t, smem + (t % NS) * STG + wdst); };
   auto issue_v = [&](int t) {
     if constexpr (!SHARED) issue_tile(Vgb, p.ldv, voffb, false, t, smem + (NS + t % NS) * VST + wrow * DK);
   };
@@ -254,6 +262,16 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   // bytes: what the first S^T chain needs), then the other prologue stages (the loop's iteration t issues K(t+NS) and
   // V(t+NS-1), or X(t+NS-1) of the shared image) -- ONE exposed memory latency.  (Tiles behind the last valid key are
   // requested too when they fall into the prologue: harmless, they are just never read.)
+  // (the first mask word of the lane goes out FIRST: loads return in order, and the ballots below would otherwise sit
+  // behind every operand stage of the prologue)
+  uint32_t v_pre = 0x01010101u;
+  bool pre_ok = false;
+  if constexpr (key_mask) {
+    if (mrow_b != nullptr && mask_al4 && 4 * tid + 4 <= p.Sk) {
+      v_pre = *reinterpret_cast<const uint32_t*>(mrow_b + 4 * tid);
+      pre_ok = true;
+    }
+  }
   issue_k(0);
   issue_v(0);
   BMHRL_STAMP(1)
@@ -282,7 +300,9 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
     for (int j = 0; j * NW < n_words; ++j) {
       const int i0 = 4 * (tid + NT * j);
       uint32_t v = 0x01010101u;                                               // no mask: "keep"
-      if (mrow_b != nullptr && i0 < p.Sk) {
+      if (j == 0 && pre_ok) {
+        v = v_pre;
+      } else if (mrow_b != nullptr && i0 < p.Sk) {
         if (mask_al4 && i0 + 4 <= p.Sk) {
           v = *reinterpret_cast<const uint32_t*>(mrow_b + i0);
         } else {
@@ -335,21 +355,21 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
     for (int sec = 0; sec < (SHARED ? 2 : 1); ++sec) {
       const int lc = 4 * dd + 2 * g1 + (p4 >> 1);
       const int pc = SHARED ? (lc ^ ((q4 << 2) | ((h + 2 * sec) & 3))) : (lc ^ (q4 << 2));
-      v_addr[dd][sec] = lds0 + VBASE + 2 * ((32 * ki + 4 * h + q4) * DK) + (pc << 4) + ((p4 & 1) << 3);
+      v_addr[dd][sec] = lds0 + VBASE + 2 * (ki * KSB + (4 * h + q4) * DK) + (pc << 4) + ((p4 & 1) << 3);
     }
   //   K fragments: row 32 ki + r32, logical chunk 2 st + h; steps st and st + 8 are 256 bytes apart (DK = 256), so 8
   //   addresses + an immediate cover the 16 steps
   unsigned k_addr[8];
 #pragma unroll
   for (int st = 0; st < 8; ++st)
-    k_addr[st] = lds0 + 2 * ((32 * ki + r32) * DK) + (((2 * st + h) ^ swz_k(r32)) << 4);
+    k_addr[st] = lds0 + 2 * (ki * KSB + r32 * DK) + (((2 * st + h) ^ swz_k(r32)) << 4);
 
   // scale + mask the raw scores of one tile through per-key coefficients (masked / padding keys): the mask bytes of the
   // lane's 16 keys come straight from global memory (rare path); returns the tile maximum over the lane pair
   //   valid key  : coef = scale*log2(e), pen = 0        masked key : coef = 0, pen = -1e9*log2(e)
   //   key >= Sk  : coef = 0, pen = -inf  (tile padding)
   const float c_log2 = p.scale * LOG2E;
-  auto scale_scores = [&](const f32x16& raw, f32x16& sc, const int k0) {
+  auto scale_scores = [&](const f32x16& raw, float (&sc)[16], const int k0) {
     float m_tile = -INFINITY;
     const int key0 = k0 + 32 * ki + 4 * h;
 #pragma unroll
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   // lazy rescale (only when some row's max grew by more than RESCALE_THR): everything accumulated so far is at the old
   // max and P of the new tile has not been exponentiated yet, so O and l are scaled exactly once
   // `fix_args`: the exponential arguments in `args` were already formed with the old max; shift them to the new one.
-  auto maybe_rescale = [&](const float m_tile, const bool have_o, const bool fix_args, f32x16& args) {
+  auto maybe_rescale = [&](const float m_tile, const bool have_o, const bool fix_args, float (&args)[16]) {
     if (__any(m_tile > m_run + RESCALE_THR)) {
       const float m_new = fmaxf(m_run, m_tile);
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
@@ -432,7 +452,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
     }
   };
   auto max_for_exp = [&]() { return (m_run == -INFINITY) ? 0.f : m_run; };
-  auto args_slow = [&](f32x16& sc, const float m_use) {      // sc holds scaled + masked scores
+  auto args_slow = [&](float (&sc)[16], const float m_use) {      // sc holds scaled + masked scores
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] -= m_use;
   };
@@ -440,7 +460,8 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   // ---- S^T chain of one tile: K fragments by ds_read_b128 (asm), first half of the chain starts as soon as the first
   // fragments are there; `mid` runs between the two halves (it issues the V^T reads of the tile in flight), `step(i)`
   // after MFMA i (the exponentials of the previous tile hide under the chain)
-  f32x16 s_acc, sc;
+  f32x16 s_acc;
+  float sc[16];           // scalars, not a 16-register tuple: a slice overwrites single elements in place
   bf16x8 kf[NQ];
   auto qk_issue = [&](const unsigned koffs) {
 #pragma unroll
@@ -495,8 +516,10 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   };
 
   // ---- the first tile's operands: every wave waits for its own pieces (and Q / the mask bytes), the barrier publishes
-  // them and the ballot words
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // them and the ballot words.  Shared image: the later prologue stages (issued after stage 0 and Q) stay in flight.
+  constexpr int PRO_LATER = SHARED ? (NS - 2) * GL : 0;       // pieces of stages 1 .. NS-2, when the row has that many tiles
+  if (SHARED && nt_all >= NS - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PRO_LATER) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   BMHRL_STAMP(3)
@@ -538,7 +561,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = fmaf(s_acc[r], c_log2, -m_run);
   }
-  // what the first iteration reads -- K(1), V(0) -- has landed: every wave waits for its own pieces
+  // what the first iteration reads -- K(1), V(0), and K(2) in its O^T phase -- has landed: every wave waits for its own pieces
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -585,8 +608,147 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   constexpr int NPV = NQ;                 // MFMAs of the O^T update
   constexpr int APS = 16 / NPV;           // scores per MFMA of the O^T update (2 / 1)
 
-  if constexpr (PF) qk_issue((unsigned)(1 % NS) * (VST * 2));      // K(1) fragments (a stale stage when nt == 1: never used)
+  if constexpr (PF) qk_issue((unsigned)(1 % NS) * (STG * 2));      // K(1) fragments (a stale stage when nt == 1: never used)
   BMHRL_STAMP(6)
+#ifndef BMHRL_ABL
+#define BMHRL_ABL 0      // timing ablations of the scheduled loop (tests/kbench/build_abl.sh only; any bit makes the results wrong):
+#endif                   // 1 no barrier/vmcnt wait, 2 no global->LDS loads, 4 no exp, 8 no K reads, 16 no V^T reads, 32 no O^T MFMAs,
+                         // 64 no S^T MFMAs, 128 no O^T-gap VALU
+  if constexpr (SCHED128) {
+    // ---- head dimension 128: the iteration as an explicit list of fillers per MFMA gap.  One wave per SIMD issues in
+    // order, so the 16 MFMAs of a tile (512 cycles) only run back to back when (a) nothing sits between two of them that
+    // waits (the r02 loop read the fresh S^T accumulator right behind its chain: MFMA result latency + 8 converts exposed
+    // before the first O^T MFMA), (b) every gap carries <= ~24 issue cycles, (c) LDS reads are spread over the gaps instead
+    // of issued in bursts of 8 / 16, and (d) addresses cost no VALU: the stage of every LDS access is a compile-time
+    // immediate (the loop is unrolled NS times).  Order of the LDS reads of an iteration (hand-counted lgkmcnt waits):
+    //   S^T gap i (i = 0..7):  V^T(t) fragments TR(2i), TR(2i+1) -> vf[i % 4][i / 4]
+    //   O^T gap j (j = 0..7):  K(t+2) fragment KR(j) -> kf[j]
+    // so S^T MFMA i waits for KR(i) of the previous iteration with at most (7 - i) + 2i reads behind it, and O^T MFMA j for
+    // its two TRs with at most (14 - 2j) + j behind them.
+    static_assert(!SCHED128 || ((NS - 1) * STG * 2 + 24 * DK * 2 + 16 < 65536), "stage offsets must fit the 16-bit DS immediate");
+    static_assert(!SCHED128 || NS >= 4, "K(t+2) is read while tile t+NS-1 is being loaded: they must be different stages");
+    auto exp_inplace = [&](float& v) {
+      float x = __builtin_amdgcn_exp2f(v);
+      asm volatile("" : "+v"(x));
+      v = x;
+    };
+    // what a tile needs of the running maximum, kept in registers between the (rare) rescales: -max for the exponential
+    // arguments, and the raw-score threshold beyond which the lazy rescale must run -- so a tile's own bookkeeping is ONE
+    // compare (per lane: some lane of a pair exceeding it is exactly the pair's condition) instead of a cross-lane maximum, a
+    // multiply, an add, a compare and two selects
+    float neg_m = -max_for_exp(), thr_raw = (m_run + RESCALE_THR) / c_log2;
+    const int nt_plain = min(nt, p.Sk / BN);                       // tiles loaded as whole tiles (the last one may be ragged)
+    auto iter = [&](auto s_, const int t) {
+      constexpr int S = decltype(s_)::value;                       // t % NS
+      constexpr int SOFF = S * STG * 2, KOFF2 = ((S + 2) % NS) * STG * 2;
+      if constexpr (S == NS - 1 && 64 % NS == 0) {
+        if ((t & 63) == 63) slow_bits = slow_window(t + 1);        // (rare: Sk > 64 tiles)
+      } else if constexpr (64 % NS != 0) {
+        if ((t & 63) == 63) slow_bits = slow_window(t + 1);
+      }
+      const int t_k = t + NS - 1;
+      if (!(BMHRL_ABL & 2) && p.dbg != 1) {
+        bf16_t* sdst = smem + ((S + NS - 1) % NS) * STG + wdst;
+        if (t_k < nt_plain) {                                      // whole tile: one uniform base, immediate piece offsets
+          const char* base = Kgb + ((long)t_k * BN + wrow) * p.ldk * 2;
+          static_for<0, GL>([&](auto i) { issue_piece(i, base, koffb, sdst); });
+        } else if (t_k < nt) {
+          issue_tile(Kgb, p.ldk, koffb, true, t_k, sdst);
+        }
+      }
+      float part = 0.f, rmx = -INFINITY;
+      const bool slow = (slow_bits >> ((t + 1) & 63)) & 1;         // wave-uniform, rare: masked / padding keys
+      // S^T(t+1) = K(t+1) . Q^T   ||  P(t) = exp2(args), V^T(t) fragment reads, first half of the bf16 P^T operand
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+      static_for<0, 8>([&](auto i_) {
+        constexpr int I = decltype(i_)::value;
+        // (one wait per two MFMAs: K fragments I and I + 1 have at most (6 - I) + 2 I younger reads behind them)
+        if constexpr (BMHRL_ABL & (8 | 16)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[I]));
+        else if constexpr (I % 2 == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[I]), "+v"(kf[I + 1]) : "n"(6 + I));
+        if constexpr (!(BMHRL_ABL & 64)) s_acc = BMHRL_MFMA16(kf[I], qf[I], s_acc, 0, 0, 0);
+        if constexpr (!(BMHRL_ABL & 4)) {
+          exp_inplace(sc[2 * I]);
+          exp_inplace(sc[2 * I + 1]);
+        }
+        if constexpr (!(BMHRL_ABL & 16)) {
+          constexpr int DD = I % 4, KS = I / 4;
+          vf[DD][KS] = join8(asm_tr4<SOFF + KS * 16 * DK * 2>(v_addr[DD][0]), asm_tr4<SOFF + (KS * 16 + 8) * DK * 2>(v_addr[DD][1]));
+        }
+        if constexpr (I >= 4) {                                    // elements 0..7 are exponentiated by gap 3
+          pf[0][2 * (I - 4)] = (bf16_t)sc[2 * (I - 4)];
+          pf[0][2 * (I - 4) + 1] = (bf16_t)sc[2 * (I - 4) + 1];
+        }
+        BMHRL_SB();
+      });
+      // O^T += V^T(t) . P^T(t)   ||  second half of P^T, row sum of P(t), K(t+2) fragment reads, and -- from gap 1 on, when the
+      // S^T chain has retired -- row max and exponential arguments of tile t+1 (in place: the slot's P was summed already)
+      auto arg = [&](const int e) {
+        float x = fmaf(s_acc[e], c_log2, neg_m);
+        asm volatile("" : "+v"(x));
+        sc[e] = x;
+      };
+      static_for<0, 8>([&](auto j_) {
+        constexpr int J = decltype(j_)::value;
+        // (V^T fragments of MFMAs J and J + 1: at most (12 - 2 J) + J younger reads behind them)
+        if constexpr (BMHRL_ABL & (8 | 16)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[J % 4][J / 4]));
+        else if constexpr (J % 2 == 0)
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vf[J % 4][J / 4]), "+v"(vf[(J + 1) % 4][(J + 1) / 4]) : "n"(12 - J));
+        if constexpr (!(BMHRL_ABL & 32)) o[J % 4] = BMHRL_MFMA16(vf[J % 4][J / 4], pf[J / 4], o[J % 4], 0, 0, 0);
+        if constexpr (!(BMHRL_ABL & 8)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[J]) : "v"(k_addr[J]), "n"(KOFF2));
+        if constexpr (BMHRL_ABL & 128) { BMHRL_SB(); return; }
+        if constexpr (J < 4) {
+          pf[1][2 * J] = (bf16_t)sc[8 + 2 * J];
+          pf[1][2 * J + 1] = (bf16_t)sc[9 + 2 * J];
+        }
+        part += sc[2 * J];
+        part += sc[2 * J + 1];
+        asm volatile("" : "+v"(part));
+        // (v_max3_f32 written out: fmaxf() costs a canonicalising v_max x, x per operand on top)
+        if constexpr (J >= 1 && J <= 5) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(rmx) : "v"(s_acc[2 * J - 2]), "v"(s_acc[2 * J - 1]));
+          arg(2 * J - 2);
+          arg(2 * J - 1);
+        } else if constexpr (J == 6) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(rmx) : "v"(s_acc[10]), "v"(s_acc[11]));
+          arg(10); arg(11); arg(12);
+        } else if constexpr (J == 7) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(rmx) : "v"(s_acc[12]), "v"(s_acc[13]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(rmx) : "v"(s_acc[14]), "v"(s_acc[15]));
+          arg(13); arg(14); arg(15);
+        }
+        BMHRL_SB();
+      });
+      l_run += part;
+      if (slow || __any(rmx > thr_raw)) {                          // rare: masked / padding keys in the tile, or the maximum grew by > 2^8
+        float m_tile = pair_max(rmx) * c_log2;
+        if (slow) {
+          m_tile = scale_scores(s_acc, sc, (t + 1) * BN);
+          args_slow(sc, -neg_m);
+        }
+        maybe_rescale(m_tile, true, true, sc);
+        neg_m = -max_for_exp();
+        thr_raw = (m_run + RESCALE_THR) / c_log2;
+      }
+      // the loads issued at the top are read as K fragments in the NEXT iteration's O^T phase (NS = 4 stages within the DS
+      // immediate's reach): they have had the whole iteration to land
+      if constexpr (BMHRL_ABL & 1) return;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    int t = 0;
+    while (true) {
+      bool done = false;
+      static_for<0, NS>([&](auto s_) {
+        if (!done) {
+          if (t + 1 < nt) { iter(s_, t); ++t; }
+          else done = true;
+        }
+      });
+      if (done) break;
+    }
+  } else
   for (int t = 0; t + 1 < nt; ++t) {
     if ((t & 63) == 63) slow_bits = slow_window(t + 1);      // (rare: Sk > 64 tiles)
     // K(t+1) fragments: their LDS latency passes under the load issue below (PF: requested during the previous
@@ -667,7 +829,7 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
   }
   BMHRL_STAMP(7)
   {   // last tile: exponentials and O^T only
-    const unsigned soff = (unsigned)((nt - 1) % NS) * (VST * 2);
+    const unsigned soff = (unsigned)((nt - 1) % NS) * (STG * 2);
     read_vt(soff, H0{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_exp2f(sc[r]);
@@ -925,10 +1087,7 @@ int attention128_entry(const void* Qp, int64_t ldq, const void* X, int64_t ldx, 
   hipError_t e;
   if (code == 41) e = launch_attn<DK, 4, 1, 4, true, true>(a, stream);
   else if (code == 22) e = launch_attn<DK, 2, 2, 4, true, true>(a, stream);
-#ifdef BMHRL_ATTN_EXPERIMENTS
-  else if (code == 24) e = launch_attn<DK, 2, 4, 3, true, true>(a, stream);
-  else if (code == 14) e = launch_attn<DK, 1, 4, 3, true, true>(a, stream);
-#endif
+  else if (code == 24) e = launch_attn<DK, 2, 4, 4, true, true>(a, stream);      // eight waves: two per SIMD at 64 rows per CU
   else return -22;
   attn_trace_dump("attn128", Sq, Sk, stream);
   return hip_status(e);

@@ -21,6 +21,7 @@ def test_split_backward_equals_single_phase():
         t = CaptionTrainer(syn.default_cfg(dout_p=0.0), 300, dev, lr=1e-3)
         t.agent.train()
         t.split_backward = split
+        init = t.opt.flat.clone()
         t.capture(fs, cap, warmup=2)
         losses = [float(t.replay()) for _ in range(3)]
         assert hasattr(t, "graph_a2") == split
@@ -28,12 +29,22 @@ def test_split_backward_equals_single_phase():
             assert len(t.graph_a2) == 2 and len(t.opt.bucket_bounds) == 4          # N = 2 encoder layers -> 3 buckets
             assert all(b > a for a, b in zip(t.opt.bucket_bounds, t.opt.bucket_bounds[1:]))
         runs.append((losses, t.opt.flat.clone(), t.opt.split_off, t.opt.n))
+        bounds1 = [t.opt._elem_off(i) for i in t.opt.bucket_bounds]           # element ranges of the buckets (same order in every run)
     (l0, p0, _, _), (l0b, p0b, _, _), (l1, p1, off, n) = runs
     assert 0 < off < n                                   # both buckets are non-empty
     # Separately built trainers differ by the arrival order of fp32 atomics (split-K weight gradients, column sums), and
     # Adam turns the sign noise of near-zero gradients (key biases) into +-lr moves: the split run must sit inside the
     # spread of two single-phase runs.
+    # Measured on MI355X over several boxes (tests/probes/diag_split.py): single vs single 0.6e-3 .. 1.6e-3 of |p|, single vs
+    # split 1.4e-3 .. 1.8e-3 -- one population (five Adam steps of lr 1e-3 move a parameter whose gradient sign is noise by up
+    # to 5e-3 against weights of ~3e-2); a phase that lost its gradients or its update would show as >= 1e-1 on its bucket.
     spread_l = max(abs(a - c) / abs(a) for a, c in zip(l0, l0b))
     spread_p = float((p0 - p0b).norm() / p0.norm())
     assert all(abs(a - c) / abs(a) < max(1e-3, 3 * spread_l) for a, c in zip(l0, l1)), (l0, l0b, l1)
-    assert float((p0 - p1).norm() / p0.norm()) < max(1e-4, 3 * spread_p), (spread_p, float((p0 - p1).norm() / p0.norm()))
+    d_split = float((p0 - p1).norm() / p0.norm())
+    assert d_split < max(3e-3, 3 * spread_p), (spread_p, d_split)
+    # every bucket of the split run moved as far from the initial weights as the single-phase run did (no phase was dropped)
+    for lo, hi in zip(bounds1, bounds1[1:]):
+        moved0 = float((p0[lo:hi] - init[lo:hi]).norm())
+        moved1 = float((p1[lo:hi] - init[lo:hi]).norm())
+        assert moved0 > 0 and abs(moved1 - moved0) <= 5e-2 * moved0, (lo, hi, moved0, moved1)
