@@ -1017,5 +1017,5 @@ extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
 // 7: bmhrl_adam_segments   8: bmhrl_gemm_desc.colsum_sb1 / bias_sb1, fp16 attention entry points   9: bmhrl_make_masks
 // 10: bmhrl_softmax_bwd_rows, bmhrl_cast_split3_bf16 (+ split shadows in the segment tables), DSCORE honours the mask,
-//     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys
+//     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce
 extern "C" int bmhrl_hip_abi_version(void) { return 10; }

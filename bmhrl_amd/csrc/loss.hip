@@ -230,6 +230,36 @@ __global__ void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const fl
 }
 
 // Inverse-CDF categorical sample with one uniform per row (or arg-max), block per row.
+// loss = weight * sum(row_loss) / n_tokens and scale = weight / n_tokens (what the backward multiplies every row by), with
+// n_tokens = #(trg != pad): the reduction epoch_loops/captioning_bmrl_loops.py:1156-1158 (warmstart) / :846-847,859 (RL, with
+// `factor` = 4/20) does with torch.sum / n_tokens.  One block; rows = B*L is a few hundred.
+__global__ void token_loss_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ trg, long rows, int64_t pad,
+                                         const float* __restrict__ weight, float factor, float* __restrict__ loss,
+                                         float* __restrict__ scale) {
+  __shared__ float s_sum[256];
+  __shared__ float s_cnt[256];
+  float a = 0.f, c = 0.f;
+  for (long i = threadIdx.x; i < rows; i += blockDim.x) {
+    a += row_loss[i];
+    c += trg[i] != pad ? 1.f : 0.f;
+  }
+  s_sum[threadIdx.x] = a;
+  s_cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+      s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float w = (weight ? weight[0] : 1.f) / (s_cnt[0] * factor);
+    loss[0] = s_sum[0] * w;
+    scale[0] = w;
+  }
+}
+
 __global__ void sample_kernel(const float* __restrict__ logp, long ld, int64_t* __restrict__ out, float* __restrict__ p_out,
                               int V, int greedy, uint64_t seed, const uint64_t* __restrict__ seed_dev, long row_offset) {
   if (seed_dev) seed += seed_dev[0];          // a device word advanced per step: fresh samples under graph replay
@@ -336,6 +366,14 @@ extern "C" int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t*
   BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
   hipLaunchKernelGGL(smooth_kl_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
                      score, n_row, smoothing, pad_idx, zero_pad_rows, row_loss, amp_out, (long)rows, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_token_loss_reduce(const float* row_loss, const int64_t* trg, int64_t rows, int64_t pad_idx, const float* weight,
+                                      float factor, float* loss, float* scale, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(row_loss && trg && loss && scale && rows > 0 && factor > 0.f);
+  hipLaunchKernelGGL(token_loss_reduce_kernel, dim3(1), dim3(256), 0, S_(stream), row_loss, trg, (long)rows, pad_idx, weight, factor,
+                     loss, scale);
   return hip_status(hipGetLastError());
 }
 

@@ -1450,6 +1450,42 @@ class SmoothKLFn(torch.autograd.Function):
         return g.view(B, S, V), None, None, None, None, None, None
 
 
+class TokenLossFn(torch.autograd.Function):
+    """weight * sum(LabelSmoothing / BiasedKL rows) / (n_tokens * factor) as ONE autograd node -- the reduction the loops
+    write as `torch.sum(criterion(pred, y)) / n_tokens` (epoch_loops/captioning_bmrl_loops.py:1156-1158; `/ (n_tokens *
+    loss_factor)` at :846-862).  Same kernels as SmoothKLFn; the token count, the division and the data-parallel weight are
+    a one-block reduce, and the backward hands its scalar straight to the gradient kernel (no (rows, V) multiply pass)."""
+
+    @staticmethod
+    def forward(ctx, logp, trg, biased_trg, score, n_row, smoothing, pad_idx, factor, weight):
+        B, S, V = logp.shape
+        rows = B * S
+        dev = logp.device
+        logp = logp.contiguous()
+        trg = trg.contiguous().view(-1)
+        bt = biased_trg.contiguous().view(-1) if biased_trg is not None else None
+        sc = score.contiguous().view(-1).float() if score is not None else None
+        nr = n_row.contiguous().view(-1).float() if n_row is not None else None
+        row_loss = torch.empty(rows, device=dev)
+        amp = torch.empty(rows, device=dev) if bt is not None else None
+        ops.smooth_kl_fwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, row_loss, amp, rows, V)
+        out = torch.empty(2, device=dev)                     # [loss, scale]
+        ops.token_loss_reduce(row_loss, trg, rows, pad_idx, weight, float(factor), out[0:1], out[1:2])
+        ctx.save_for_backward(logp, trg, bt, sc, nr, out)
+        ctx.cfg = (B, S, V, smoothing, pad_idx)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        B, S, V, smoothing, pad_idx = ctx.cfg
+        logp, trg, bt, sc, nr, out = ctx.saved_tensors
+        rows = B * S
+        g = torch.empty(rows, V, device=logp.device)
+        scale = out[1:2] * dloss.reshape(1)                  # (one element)
+        ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, scale, None, 0, g, rows, V, wrt_logits=False)
+        return g.view(B, S, V), None, None, None, None, None, None, None, None
+
+
 class ManagerKLFn(torch.autograd.Function):
     """BiasedKL of the manager branch of biased_kl() (epoch_loops/captioning_bmrl_loops.py:299-334): the amplitude of a
     position is clamp(score * PROD_{j in its segment} p(a_j) * n_segments, 0, 1) -- the product of the arg-max tokens'

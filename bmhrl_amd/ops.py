@@ -256,6 +256,13 @@ def smooth_kl_amp_grad(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_i
                                                     stream()), "bmhrl_smooth_kl_amp_grad")
 
 
+def token_loss_reduce(row_loss, trg, rows, pad_idx, weight, factor, loss, scale):
+    """loss = weight * sum(row_loss) / (#(trg != pad) * factor); scale = weight / (#tokens * factor) (device scalars)"""
+    _need_cuda(row_loss, trg, loss, scale)
+    _lib.check(_lib.load().bmhrl_token_loss_reduce(row_loss.data_ptr(), trg.data_ptr(), rows, pad_idx, _p(weight), factor,
+                                                   loss.data_ptr(), scale.data_ptr(), stream()), "bmhrl_token_loss_reduce")
+
+
 def log_softmax_bwd(dlogp, logp, ld, g_bf16, ldg, rows, V):
     _lib.check(_lib.load().bmhrl_log_softmax_bwd(dlogp.data_ptr(), logp.data_ptr(), ld, g_bf16.data_ptr(), ldg, rows, V, stream()),
                "bmhrl_log_softmax_bwd")

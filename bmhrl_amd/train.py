@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, synthetic as syn
-from .functional import SCRATCH, SEEDS, SHADOWS, ScratchState
+from .functional import SCRATCH, SEEDS, SHADOWS, ScratchState, TokenLossFn
 from .loss.biased_kl import BiasedKL
 from .loss.label_smoothing import LabelSmoothing
 from .model.bm_hrl_agent import BMHrlAgent, BMManagerValueFunction, BMWorkerValueFunction
@@ -359,6 +359,11 @@ class CaptionTrainer:
         else:
             masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
         pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
+        if self.phase == "warmstart" and rl is None and pred.is_cuda:
+            # sum(LabelSmoothing) / n_tokens (x the rank's token weight) as one node: functional.TokenLossFn
+            w = self.loss_weight if self._world_scale() != 1.0 else None
+            return TokenLossFn.apply(pred, trg_y, None, None, None, float(self.criterion.smoothing), int(self.criterion.pad_idx),
+                                     1.0, w), pred
         loss_mask = trg_y != self.pad_idx
         n_tokens = loss_mask.sum()
         if self.phase != "warmstart":

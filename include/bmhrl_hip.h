@@ -251,6 +251,11 @@ int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const
                         const float* score, const float* n_row, float smoothing, int32_t pad_idx,
                         int32_t zero_pad_rows, const float* loss_scale /* device scalar */, int32_t wrt_logits,
                         void* grad_bf16, int64_t ldg, float* grad_f32, int64_t rows, int32_t V, bmhrl_stream_t stream);
+/* The loops' reduction of the row sums: loss = weight * sum(row_loss) / (n_tokens * factor), n_tokens = #(trg != pad_idx)
+ * (epoch_loops/captioning_bmrl_loops.py:1156-1158: factor 1; :829-833,846-862: factor 4/20); scale = weight / (n_tokens *
+ * factor) is what bmhrl_smooth_kl_bwd takes as loss_scale.  weight: optional device scalar (data-parallel token weight). */
+int bmhrl_token_loss_reduce(const float* row_loss, const int64_t* trg, int64_t rows, int64_t pad_idx, const float* weight,
+                            float factor, float* loss, float* scale, bmhrl_stream_t stream);
 int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, void* dlogits_bf16, int64_t ldg,
                           int64_t rows, int32_t V, bmhrl_stream_t stream);
 /* out[row] = d rowloss / d log(raw amplitude) (0 where clamp(., 0, 1) is active): the share of the gradient that reaches the

@@ -591,3 +591,28 @@ def test_make_masks_kernel_equals_the_reference_functions(dev):
             assert got.dtype == torch.bool and got.shape[0] == copies * 5
             assert torch.equal(got, torch.cat([want] * copies))
     assert not bool(ref["V_mask"].all()) and not bool(ref["C_mask"][:, -1].all())      # padding is present in the case
+
+
+def test_token_loss_node_equals_sum_over_n_tokens(dev, golden):
+    """functional.TokenLossFn (row sums -> one-block reduce -> scalar, gradient scaled inside the kernel) == the loops'
+    torch.sum(criterion(pred, y)) / (n_tokens * factor) over SmoothKLFn, value and gradient; against the oracle too."""
+    from bmhrl_amd.functional import SmoothKLFn, TokenLossFn
+    from oracle import bmhrl_oracle as O
+    g = golden("losses")
+    logits, trg = torch.from_numpy(g["logits"]).to(dev), torch.from_numpy(g["trg"]).to(dev)
+    sampled, score = torch.from_numpy(g["sampled"]).to(dev), torch.from_numpy(g["score"]).to(dev)
+    n_row = (trg != 1).sum(-1, keepdim=True).float().expand_as(trg).contiguous()
+    for bt, sc, nr, factor, w in ((None, None, None, 1.0, None), (sampled, score, n_row, 0.2, torch.tensor([1.25], device=dev))):
+        x = logits.clone().requires_grad_(True)
+        loss = TokenLossFn.apply(torch.log_softmax(x, -1), trg, bt, sc, nr, 0.7, 1, factor, w)
+        (loss * 3.0).backward()
+        y = logits.clone().requires_grad_(True)
+        rows, _ = SmoothKLFn.apply(torch.log_softmax(y, -1), trg, bt, sc, nr, 0.7, 1)
+        ref = rows.sum() / ((trg != 1).sum() * factor) * (1.0 if w is None else w[0])
+        (ref * 3.0).backward()
+        assert rel_err(loss, ref) < 1e-6 and rel_err(x.grad, y.grad) < 1e-5
+    z = torch.from_numpy(g["logits"]).requires_grad_(True)
+    ref = O.warmstart_loss(torch.log_softmax(z, -1), torch.from_numpy(g["trg"]), 0.7, 1)
+    x = logits.clone().requires_grad_(True)
+    loss = TokenLossFn.apply(torch.log_softmax(x, -1), trg, None, None, None, 0.7, 1, 1.0, None)
+    assert rel_err(loss, ref.detach()) < 1e-5
