@@ -39,29 +39,31 @@ def mask(src, trg, pad_idx, data_pad=0):
     return src_mask, c_mask(trg, pad_idx)
 
 
+# which padding masks a modality string asks for: mask key -> (feature stack, takes the first feature column?)
+_SOURCES = {
+    'video': {'V_mask': ('rgb', True)},
+    'audio': {'A_mask': ('audio', True)},
+    'audio_video': {'V_mask': ('rgb', True), 'A_mask': ('audio', True)},
+    'subs_audio_video': {'V_mask': ('rgb', True), 'A_mask': ('audio', True), 'S_mask': ('subs', False)},
+}
+
+
 def make_masks(feature_stacks, captions, modality, pad_idx):
-    """reference :28-55.  V_mask comes from rgb[:, :, 0] (before flow is added), A_mask from audio[:, :, 0]."""
+    """reference :28-55 as a table: every stack of the modality gets its key-padding mask from its FIRST feature column
+    (`rgb[:, :, 0]`, taken before the flow is added; `audio[:, :, 0]`; subtitles are token ids already), and the caption
+    mask `C_mask` is added when captions are given."""
+    try:
+        wanted = _SOURCES[modality]
+    except KeyError:
+        raise ValueError(f'unknown modality {modality}') from None
     masks = {}
-    if modality == 'video':
-        if captions is None:
-            masks['V_mask'] = mask(feature_stacks['rgb'][:, :, 0], None, pad_idx)
-        else:
-            masks['V_mask'], masks['C_mask'] = mask(feature_stacks['rgb'][:, :, 0], captions, pad_idx)
-    elif modality == 'audio':
-        assert len(feature_stacks['audio'].shape) == 3
-        if captions is None:
-            masks['A_mask'] = mask(feature_stacks['audio'][:, :, 0], None, pad_idx)
-        else:
-            masks['A_mask'], masks['C_mask'] = mask(feature_stacks['audio'][:, :, 0], captions, pad_idx)
-    elif modality in ('audio_video', 'subs_audio_video'):
-        assert len(feature_stacks['audio'].shape) == 3
-        if captions is None:
-            masks['V_mask'] = mask(feature_stacks['rgb'][:, :, 0], None, pad_idx)
-        else:
-            masks['V_mask'], masks['C_mask'] = mask(feature_stacks['rgb'][:, :, 0], captions, pad_idx)
-        masks['A_mask'] = mask(feature_stacks['audio'][:, :, 0], None, pad_idx)
-        if modality == 'subs_audio_video':
-            masks['S_mask'] = mask(feature_stacks['subs'], None, pad_idx)
-    else:
-        raise ValueError(f'unknown modality {modality}')
+    for key, (stack, first_column) in wanted.items():
+        feats = feature_stacks[stack]
+        if first_column:
+            if feats.dim() != 3:
+                raise ValueError(f'{stack} features must be (B, T, D), got {tuple(feats.shape)}')
+            feats = feats[:, :, 0]
+        masks[key] = mask(feats, None, pad_idx)
+    if captions is not None:
+        masks['C_mask'] = c_mask(captions, pad_idx)
     return masks
