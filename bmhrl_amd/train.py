@@ -130,6 +130,16 @@ class FlatAdam:
             d = dst.get(id(p), (0, 1, sz, 0))
             rows.append([o, d[0], d[1], d[2], d[3], blk, gptrs[i] if gptrs is not None else 0])
             blk += (sz + ops.SEG_ELEMS_PER_BLOCK - 1) // ops.SEG_ELEMS_PER_BLOCK
+        # one table per bucket as well (first-block column rebased): the update of a bucket can be launched as soon as its
+        # gradients are complete (CaptionTrainer, phased Adam), while backward goes on below it
+        parts = []
+        bounds = self.__dict__.get("bucket_bounds")
+        if bounds is not None:
+            for lo, hi in zip(bounds, bounds[1:]):
+                sub = [r[:5] + [r[5] - rows[lo][5]] + r[6:] for r in rows[lo:hi]]
+                nblk = (rows[hi][5] if hi < len(rows) else blk) - (rows[lo][5] if lo < len(rows) else blk)
+                parts.append((torch.tensor(sub, dtype=torch.int64).to(dev) if sub else None, len(sub), nblk))
+        self._part_plans = parts
         plan = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), blk, uncovered)
         self._seg_plan = (sig, plan, gptrs)
         self.maintained = {(kind, key) for kind, key, _, _, _ in groups if (kind, key) not in set(uncovered)}
@@ -161,9 +171,21 @@ class FlatAdam:
         segmented copy kernel (bmhrl_cast_segments, fp32 mode): inside a trainer step the gradients live at fixed
         addresses (slices of the step scratch arena), so the segment table is built once and reused.
         part: None = all parameters, i = bucket i of set_buckets() / set_split()."""
+        one_rank = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if part is not None and one_rank and self.direct_grads and self.fused_shadows and self.flat.is_cuda and \
+                self.__dict__.get("phased_direct", False):
+            # one rank, phased Adam: the bucket's gradients stay where autograd left them.  Before the plan exists (first
+            # warm-up pass) there is nothing to do -- the full gather_grads() at the end of that pass records the addresses;
+            # afterwards the addresses of this bucket must be the recorded ones (they are slices of the trainer's scratch arena)
+            cached = self.__dict__.get("_seg_plan")
+            if cached is not None and cached[2] is not None:
+                lo, hi = self._bucket_range(part)
+                ptrs = tuple(0 if p.grad is None else p.grad.data_ptr() for p in self.params[lo:hi])
+                if ptrs != tuple(cached[2][lo:hi]):
+                    raise RuntimeError("phased Adam: a gradient moved since the plan was built (bucket %d)" % part)
+            return
         self._direct_ptrs = None
-        if part is None and self.direct_grads and self.fused_shadows and self.flat.is_cuda and \
-                not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if part is None and self.direct_grads and self.fused_shadows and self.flat.is_cuda and one_rank:
             # one process: nothing needs the gradients side by side -- the Adam pass reads each one where autograd left it
             ptrs = tuple(0 if p.grad is None else
                          (p.grad.data_ptr() if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else -1)
@@ -217,6 +239,22 @@ class FlatAdam:
             if hi > lo:
                 return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
         return None
+
+    def step_part(self, part: int, grad_scale: float = 1.0):
+        """the update of bucket `part` alone (its gradients are complete; later buckets are still in backward).  Needs the
+        plan of a previous full step(); the step counters advance with bucket 0."""
+        b1, b2 = self.betas
+        if part == 0:
+            self.step_count += 1
+            self.generation += 1
+            self.step_dev.add_(1)
+        table, n_seg, n_blk = self._part_plans[part]
+        if n_seg:
+            ops.adam_segments(table, n_seg, n_blk, self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, b1, b2, self.eps,
+                              self.weight_decay, self.step_count, grad_scale, step_dev=self.step_dev)
+        if part == len(self._part_plans) - 1:
+            for kind, key in self._seg_plan[1][3]:
+                SHADOWS.mark_stale(kind, key)
 
     def step(self, grad_scale: float = 1.0):
         self.step_count += 1
@@ -336,9 +374,15 @@ class CaptionTrainer:
         self.phase_params = [early] + [per_layer[i] for i in reversed(range(n_enc))]
         self.opt = FlatAdam([p for ph in self.phase_params for p in ph], lr=lr, weight_decay=weight_decay)
         self.opt.set_buckets([len(ph) for ph in self.phase_params])
+        self.opt.phased_direct = False      # set by capture() in the one-rank phased mode: gather_grads(bucket) leaves gradients in place
         self.early_params = early
         self.n_enc = n_enc
         self.split_backward = None          # None: split when a process group with more than one rank is active
+        # one rank, optional (BMHRL_PHASED_ADAM=1): the backward runs in the same phases inside ONE graph and every bucket's
+        # Adam pass starts on a side stream as soon as its phase is done, so the 221 MB update streams under the encoder's
+        # backward.  Measured on MI355X at config 2: 5.88 ms against 5.73 ms for the plain step -- the phase boundaries join
+        # every side stream of the backward three times and cost more than the 0.2 ms of Adam they hide; off by default.
+        self.phased_adam = os.environ.get("BMHRL_PHASED_ADAM", "0") == "1"
         self._layer_out = {}
         for i, layer in enumerate(enc_layers):   # (V-stream, A-stream) after layer i: the cut between two backward phases
             layer.register_forward_hook(lambda mod, inp, out, i=i: self._layer_out.__setitem__(i, out))
@@ -433,6 +477,7 @@ class CaptionTrainer:
 
     # ------------------------------------------------------------------ whole-step HIP graph
     _warm_streams = {}
+    _adam_streams = {}
 
     def capture(self, fs, captions, warmup: int = 3):
         """Capture step() for static shapes; afterwards replay(fs, captions) copies the inputs into the captured
@@ -441,6 +486,7 @@ class CaptionTrainer:
         self.static = {k: v.clone() for k, v in fs.items()}
         self.static["captions"] = captions.clone()
         self.static_loss = torch.zeros((), device=self.device)
+        self.opt.phased_direct = self._phased_one_rank()
         s = CaptionTrainer._warm_streams.get(self.device)      # one warm-up stream per device and process (the pool of 32 wraps)
         if s is None:
             s = CaptionTrainer._warm_streams[self.device] = torch.cuda.Stream(device=self.device)
@@ -463,6 +509,8 @@ class CaptionTrainer:
                 if self._split():
                     for j in range(1, self.n_enc + 1):
                         self._graph_body_phase(j)
+                if self._phased_one_rank():
+                    self.opt.gather_grads()                 # records where every gradient lives: the plan of the phased passes
                 scale = self.opt.all_reduce()               # warm-up steps are real steps: replicas stay identical
                 if self.value_net is not None:
                     self.vopt.all_reduce()
@@ -471,11 +519,28 @@ class CaptionTrainer:
                                               # copy, not allowed while capturing); the captured body reuses it
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        alone = self._world_scale() == 1.0 and not self._split()
+        phased = self._phased_one_rank()
+        alone = self._world_scale() == 1.0 and (phased or not self._split())
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self._graph_body_a()
-            if alone:                         # no all-reduce to leave room for: the optimizer joins the same graph
+            if phased:
+                # ONE graph: backward phase j on the capture stream, the Adam pass of bucket j - 1 beside it on a side
+                # stream (forked from and joined into the capture stream only: DESIGN.md section 10)
+                main = torch.cuda.current_stream()
+                side = CaptionTrainer._adam_streams.get(self.device)
+                if side is None:
+                    side = CaptionTrainer._adam_streams[self.device] = torch.cuda.Stream(device=self.device)
+                for j in range(1, self.n_enc + 1):
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self.opt.step_part(j - 1, 1.0)
+                    self._graph_body_phase(j)
+                main.wait_stream(side)
+                self.opt.step_part(self.n_enc, 1.0)
+                if self.value_net is not None:
+                    self.vopt.step(1.0)
+            elif alone:                       # no all-reduce to leave room for: the optimizer joins the same graph
                 self._graph_body_b(1.0)
         if alone:
             self.graph_b = None
@@ -497,7 +562,13 @@ class CaptionTrainer:
     def _world_scale():
         return 1.0 / dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1.0
 
+    def _phased_one_rank(self) -> bool:
+        return self.phased_adam and self.split_backward is None and self._world_scale() == 1.0 and self.device.type == "cuda" \
+            and self.opt.direct_grads and self.opt.fused_shadows and os.environ.get("BMHRL_SPLIT_BACKWARD") is None
+
     def _split(self) -> bool:
+        if self._phased_one_rank():
+            return True
         if self.split_backward is None:
             import os
             if os.environ.get("BMHRL_SPLIT_BACKWARD") in ("0", "1"):      # tuning / rehearsal override

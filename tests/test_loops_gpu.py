@@ -119,6 +119,27 @@ def test_trainer_graph_replay_matches_eager(setup):
         assert float(t2.opt.grad.abs().max()) == 0.0
 
 
+def test_phased_adam_graph_equals_the_plain_graph(setup):
+    """CaptionTrainer.phased_adam (one rank): backward in phases inside one graph, each bucket's Adam pass on a side stream as
+    soon as its gradients are complete (FlatAdam.step_part) == the plain captured step."""
+    from bmhrl_amd.train import CaptionTrainer
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    b = ds.batches[0]
+    cap = b["caption_data"].caption
+    out = []
+    for phased in (False, True):
+        t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+        t.agent.train()
+        t.phased_adam = phased
+        t.capture(b["feature_stacks"], cap, warmup=1)
+        assert t._split() == phased and t.graph_b is None
+        out.append(([float(t.replay()) for _ in range(3)], t.opt.flat.clone(), int(t.opt.step_dev)))
+    (l0, p0, n0), (l1, p1, n1) = out
+    assert n0 == n1 == 4                                             # one warm-up step + three replays, counted once per step
+    assert all(abs(a - c) < 2e-3 * abs(a) for a, c in zip(l0, l1)), (l0, l1)
+    assert float((p0 - p1).norm() / p0.norm()) < 3e-3
+
+
 def test_trainer_rl_graph_replay_matches_eager(setup):
     """The worker RL step (sampled tokens + synthetic rewards + value head) captured as one HIP graph == the eager step:
     the sampler adds the device seed word, so replay k draws the same tokens as eager step k."""
