@@ -23,6 +23,12 @@ class RnnLayer(C.Structure):
                 ("arelu_alpha", C.c_void_p), ("arelu_beta", C.c_void_p), ("xproj", C.c_void_p)]
 
 
+class FusionTailParams(C.Structure):
+    """bmhrl_fusion_tail_params of include/bmhrl_hip.h"""
+    _fields_ = [(n, C.c_void_p) for n in ("gamma_ca", "beta_ca", "gamma_cv", "beta_cv", "a_v",
+                                          "dgamma_ca", "dbeta_ca", "dgamma_cv", "dbeta_cv", "da_v")]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", i32), ("N", i32), ("K", i32), ("batch1", i32), ("batch2", i32),
@@ -70,6 +76,8 @@ PROTOTYPES = {
     "bmhrl_colsum_bf16": [ptr, i64, ptr, i32, i64, i32, ptr],
     "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_gate_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
+    "bmhrl_fusion_tail_fwd": [ptr, ptr, ptr, i32, i64, i32, ptr, ptr, ptr],
+    "bmhrl_fusion_tail_bwd": [ptr, ptr, ptr, ptr, ptr, i32, i64, i32, ptr, ptr, ptr],
     "bmhrl_expand_goals_index": [ptr, ptr, i32, i32, ptr],
     "bmhrl_gather_rows": [ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_scatter_add_rows": [ptr, ptr, ptr, i64, i32, ptr],

@@ -598,6 +598,132 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// ---- tail of a BMFusionLayer in one launch (model/bm_hrl_agent.py:107-114): out = g * LN_CV(cv) + (1 - g) * LN_CA(ca),
+// g = sigmoid(clamp(a_v, -2, 2)), for up to two parameter groups (the worker and the manager stack advance together as one
+// (2, B, L, D) activation: group = row / rows_per_group).  One wave per row, the row in registers (NC columns per lane).
+struct TailTable {
+  bmhrl_fusion_tail_params g[2];
+};
+template <int NC>
+__global__ void fusion_tail_fwd_kernel(const float* __restrict__ ca, const float* __restrict__ cv, const TailTable T, long rows_per_group,
+                                       int n_groups, int D, float* __restrict__ out, float* __restrict__ stats) {
+  const long rows = rows_per_group * n_groups;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const bmhrl_fusion_tail_params& P = T.g[row / rows_per_group];
+  const float gate = gate_of(P.a_v);
+  float xa[NC], xv[NC];
+  float sa = 0.f, sv = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    xa[i] = c < D ? ca[row * D + c] : 0.f;
+    xv[i] = c < D ? cv[row * D + c] : 0.f;
+    sa += xa[i];
+    sv += xv[i];
+  }
+  const float ma = wave_sum(sa) / D, mv = wave_sum(sv) / D;
+  float qa = 0.f, qv = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      qa += (xa[i] - ma) * (xa[i] - ma);
+      qv += (xv[i] - mv) * (xv[i] - mv);
+    }
+  }
+  const float ra = rsqrtf(wave_sum(qa) / D + 1e-5f), rv = rsqrtf(wave_sum(qv) / D + 1e-5f);
+  if (lane == 0) {
+    stats[row] = ma; stats[rows + row] = ra; stats[2 * rows + row] = mv; stats[3 * rows + row] = rv;
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      const float ya = (xa[i] - ma) * ra * P.gamma_ca[c] + P.beta_ca[c];
+      const float yv = (xv[i] - mv) * rv * P.gamma_cv[c] + P.beta_cv[c];
+      out[row * D + c] = gate * yv + (1.f - gate) * ya;
+    }
+  }
+}
+
+// backward of the same: dca / dcv, and (atomic +=, zeroed by the caller) d gamma / d beta of both norms and d a_v of the row's
+// group.  A block walks RPB rows of ONE group (blockIdx.y); its four waves keep per-column partial sums in registers and add
+// them up through LDS: one atomic per column and block.
+constexpr int TAIL_RPB = 16, TAIL_MAXD = 512;   // (4 rows per wave: 60 blocks per group at 480 rows; 64 rows per block ran 15 us on 16 CUs)
+template <int NC>
+__global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ ca,
+                                                              const float* __restrict__ cv, const float* __restrict__ stats,
+                                                              const TailTable T, long rows_per_group, int n_groups, int D,
+                                                              float* __restrict__ dca, float* __restrict__ dcv) {
+  __shared__ float red[4][4][64 * NC];
+  __shared__ float red_a[4];
+  const long rows = rows_per_group * n_groups;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = blockIdx.y;
+  const bmhrl_fusion_tail_params& P = T.g[grp];
+  const float a = P.a_v[0], gate = gate_of(P.a_v);
+  float dga[NC], dba[NC], dgv[NC], dbv[NC], ga[NC], gv[NC], ba[NC], bv[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    dga[i] = dba[i] = dgv[i] = dbv[i] = 0.f;
+    ga[i] = c < D ? P.gamma_ca[c] : 0.f;
+    gv[i] = c < D ? P.gamma_cv[c] : 0.f;
+    ba[i] = c < D ? P.beta_ca[c] : 0.f;
+    bv[i] = c < D ? P.beta_cv[c] : 0.f;
+  }
+  float da = 0.f;
+  const long r_end = min((long)(blockIdx.x + 1) * TAIL_RPB, rows_per_group);
+  for (long r = (long)blockIdx.x * TAIL_RPB + wave; r < r_end; r += 4) {
+    const long row = grp * rows_per_group + r;
+    const float ma = stats[row], ra = stats[rows + row], mv = stats[2 * rows + row], rv = stats[3 * rows + row];
+    float ha[NC], hv[NC], d[NC];
+    float s1a = 0.f, s2a = 0.f, s1v = 0.f, s2v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      const bool in = c < D;
+      ha[i] = in ? (ca[row * D + c] - ma) * ra : 0.f;
+      hv[i] = in ? (cv[row * D + c] - mv) * rv : 0.f;
+      d[i] = in ? dout[row * D + c] : 0.f;
+      const float dya = (1.f - gate) * d[i], dyv = gate * d[i];
+      da += d[i] * ((hv[i] * gv[i] + bv[i]) - (ha[i] * ga[i] + ba[i]));
+      dga[i] += dya * ha[i]; dba[i] += dya;
+      dgv[i] += dyv * hv[i]; dbv[i] += dyv;
+      s1a += dya * ga[i]; s2a += dya * ga[i] * ha[i];
+      s1v += dyv * gv[i]; s2v += dyv * gv[i] * hv[i];
+    }
+    s1a = wave_sum(s1a) / D; s2a = wave_sum(s2a) / D; s1v = wave_sum(s1v) / D; s2v = wave_sum(s2v) / D;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) {
+        dca[row * D + c] = ra * ((1.f - gate) * d[i] * ga[i] - s1a - ha[i] * s2a);
+        dcv[row * D + c] = rv * (gate * d[i] * gv[i] - s1v - hv[i] * s2v);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    red[wave][0][lane + 64 * i] = dga[i]; red[wave][1][lane + 64 * i] = dba[i];
+    red[wave][2][lane + 64 * i] = dgv[i]; red[wave][3][lane + 64 * i] = dbv[i];
+  }
+  da = wave_sum(da);
+  if (lane == 0) red_a[wave] = da;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 4 * D; idx += 256) {
+    const int k = idx / D, c = idx % D;
+    const float v = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+    float* dst = k == 0 ? P.dgamma_ca : k == 1 ? P.dbeta_ca : k == 2 ? P.dgamma_cv : P.dbeta_cv;
+    if (dst) atomicAdd(dst + c, v);
+  }
+  // d sigmoid(clamp(a)) / da = g (1 - g) on the closed interval [-2, 2], 0 outside (as bmhrl_gate_bwd)
+  if (threadIdx.x == 0 && P.da_v)
+    atomicAdd(P.da_v, (a >= -2.f && a <= 2.f) ? (red_a[0] + red_a[1] + red_a[2] + red_a[3]) * gate * (1.f - gate) : 0.f);
+}
+
 // Adam over the flat bucket, parameter by parameter, writing each updated weight's bf16 shadow (or fp32 copy: concatenated
 // biases) in the same pass: the per-step shadow refresh (cast_segments over every weight: 221 MB read again) disappears.
 // seg = 7 int64 per parameter: offset in the flat bucket (elements), shadow address (0: none), rows, cols, shadow leading
@@ -938,6 +1064,42 @@ extern "C" int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t 
   return hip_status(hipGetLastError());
 }
 
+static int tail_table(const bmhrl_fusion_tail_params* groups, int32_t n_groups, bool bwd, TailTable& T) {
+  BMHRL_CHECK_ARG(groups && (n_groups == 1 || n_groups == 2));
+  for (int i = 0; i < n_groups; ++i) {
+    const bmhrl_fusion_tail_params& g = groups[i];
+    BMHRL_CHECK_ARG(g.gamma_ca && g.beta_ca && g.gamma_cv && g.beta_cv && g.a_v);
+    (void)bwd;
+    T.g[i] = g;
+  }
+  if (n_groups == 1) T.g[1] = T.g[0];
+  return 0;
+}
+
+extern "C" int bmhrl_fusion_tail_fwd(const float* ca, const float* cv, const bmhrl_fusion_tail_params* groups, int32_t n_groups,
+                                     int64_t rows_per_group, int32_t D, float* out, float* stats, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(ca && cv && out && stats && rows_per_group > 0 && D > 0 && D <= TAIL_MAXD);
+  TailTable T;
+  if (int rc = tail_table(groups, n_groups, false, T)) return rc;
+  const long rows = rows_per_group * n_groups;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (D <= 320) hipLaunchKernelGGL(fusion_tail_fwd_kernel<5>, grid, block, 0, S_(stream), ca, cv, T, (long)rows_per_group, n_groups, D, out, stats);
+  else hipLaunchKernelGGL(fusion_tail_fwd_kernel<8>, grid, block, 0, S_(stream), ca, cv, T, (long)rows_per_group, n_groups, D, out, stats);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_fusion_tail_bwd(const float* dout, const float* ca, const float* cv, const float* stats,
+                                     const bmhrl_fusion_tail_params* groups, int32_t n_groups, int64_t rows_per_group, int32_t D,
+                                     float* dca, float* dcv, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dout && ca && cv && stats && dca && dcv && rows_per_group > 0 && D > 0 && D <= TAIL_MAXD);
+  TailTable T;
+  if (int rc = tail_table(groups, n_groups, true, T)) return rc;
+  dim3 grid((unsigned)((rows_per_group + TAIL_RPB - 1) / TAIL_RPB), (unsigned)n_groups), block(256);
+  if (D <= 320) hipLaunchKernelGGL(fusion_tail_bwd_kernel<5>, grid, block, 0, S_(stream), dout, ca, cv, stats, T, (long)rows_per_group, n_groups, D, dca, dcv);
+  else hipLaunchKernelGGL(fusion_tail_bwd_kernel<8>, grid, block, 0, S_(stream), dout, ca, cv, stats, T, (long)rows_per_group, n_groups, D, dca, dcv);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" int bmhrl_gate_fwd(const float* cv, const float* ca, const float* a_v, float* out, void* out_bf16, int64_t ldob,
                               int64_t rows, int32_t D, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(cv && ca && a_v && out && rows > 0 && D > 0);
@@ -1017,5 +1179,5 @@ extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
 // 7: bmhrl_adam_segments   8: bmhrl_gemm_desc.colsum_sb1 / bias_sb1, fp16 attention entry points   9: bmhrl_make_masks
 // 10: bmhrl_softmax_bwd_rows, bmhrl_cast_split3_bf16 (+ split shadows in the segment tables), DSCORE honours the mask,
-//     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce
+//     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce, bmhrl_fusion_tail_fwd / _bwd
 extern "C" int bmhrl_hip_abi_version(void) { return 10; }

@@ -329,9 +329,7 @@ class IncrementalDecoder:
                                   True, None)
                 Cv = self._attend(layer.enc_att_V, layer.res_layer_enc_att_V.norm, C, st["mem_v"][li], self.v_mask, self.tv_cap,
                                   True, None)
-                Ca = LayerNormFn.apply(Ca, layer.normCA.weight, layer.normCA.bias)
-                Cv = LayerNormFn.apply(Cv, layer.normCV.weight, layer.normCV.bias)
-                C = GateFn.apply(Cv, Ca, layer.a_v_constant)
+                C = layer._tail(Cv, Ca)            # normCA, normCV, gate: the kernel of the full forward (bit-identical)
             feats.append(C)
         w_feat, m_feat = feats
         # manager (:437-454, exploration off while decoding): the newest raw goal joins the buffer, expand_goals reads whole rows

@@ -1081,6 +1081,47 @@ class PairGateFn(torch.autograd.Function):
         return dcv, dca, das[0], das[1]
 
 
+class FusionTailFn(torch.autograd.Function):
+    """g * normCV(cv) + (1 - g) * normCA(ca), g = sigmoid(clamp(a_v, -2, 2)) -- the tail of BMFusionLayer.forward
+    (model/bm_hrl_agent.py:107-114) as ONE launch forward and ONE backward (two LayerNorms + the gate; it was five / six).
+    cv, ca: (..., D) of one stack, or (2, B, L, D) of the paired stacks with `groups` = 2 parameter sets
+    (normCA.weight, normCA.bias, normCV.weight, normCV.bias, a_v) x groups, passed flat."""
+
+    @staticmethod
+    def forward(ctx, cv, ca, groups, *params):
+        D = cv.shape[-1]
+        rows = cv.numel() // D
+        assert len(params) == 5 * groups and rows % groups == 0
+        cv, ca = cv.contiguous(), ca.contiguous()
+        out = torch.empty_like(cv)
+        stats = torch.empty(4, rows, device=cv.device)
+        gs = [tuple(t.detach() for t in params[5 * i:5 * i + 5]) for i in range(groups)]
+        ops.fusion_tail_fwd(ca, cv, gs, rows // groups, D, out, stats)
+        ctx.save_for_backward(cv, ca, stats, *params)
+        ctx.groups = groups
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cv, ca, stats = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        groups = ctx.groups
+        D = cv.shape[-1]
+        rows = cv.numel() // D
+        dev = cv.device
+        need = ctx.needs_input_grad
+        dcv, dca = torch.empty_like(cv), torch.empty_like(ca)
+        gs = [tuple(t.detach() for t in params[5 * i:5 * i + 5]) for i in range(groups)]
+        grads = []
+        for i in range(groups):
+            g = []
+            for j in range(5):
+                g.append(SCRATCH.f32(1 if j == 4 else D, device=dev) if need[3 + 5 * i + j] else None)
+            grads.append(tuple(g))
+        ops.fusion_tail_bwd(dout.contiguous(), ca, cv, stats, gs, grads, rows // groups, D, dca, dcv)
+        return (dcv, dca, None) + tuple(t for g in grads for t in g)
+
+
 class AttnCoreFn(torch.autograd.Function):
     """dropout( softmax(q k^T / sqrt(d_k), masked with -1e9) v ) on already projected fp32 (B,S,D) tensors, heads being
     d_k-wide column slices -- model/multihead_attention.py:7-31.  The general entry (q, k and v from three different

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import ExpandGoalsFn, GateFn, LayerNormFn, LinearFn, WorkerHeadFn
+from ..functional import ExpandGoalsFn, FusionTailFn, GateFn, LayerNormFn, LinearFn, WorkerHeadFn
 from .blocks import LayerStack, PositionalEncoder, PositionwiseFeedForward, ResidualConnection, VocabularyEmbedder, clone
 from .multihead_attention import MultiheadedAttention
 
@@ -158,20 +158,28 @@ class BMFusionLayer(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 Ca = self._memory_att(self.enc_att_A, C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, kvc)
-                Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
             Cv = self._memory_att(self.enc_att_V, C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, kvc)
-            Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
             main.wait_stream(side)
-            return GateFn.apply(Cv, Ca, self.a_v_constant), memory
+            return self._tail(Cv, Ca), memory
         Ca = self._memory_att(self.enc_att_A, C, Av, masks['A_mask'], self.res_layer_enc_att_A.norm, kvc)
         Cv = self._memory_att(self.enc_att_V, C, Va, masks['V_mask'], self.res_layer_enc_att_V.norm, kvc)
-        Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
-        Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
-        return GateFn.apply(Cv, Ca, self.a_v_constant), memory
+        return self._tail(Cv, Ca), memory
 
     branch_side_stream = True
     _side = None
     absorb_memory_projections = True
+    fused_tail = os.environ.get("BMHRL_FUSED_TAIL", "1") == "1"     # normCA, normCV and the gate as one launch (functional.FusionTailFn)
+
+    def _tail_params(self):
+        return (self.normCA.weight, self.normCA.bias, self.normCV.weight, self.normCV.bias, self.a_v_constant)
+
+    def _tail(self, Cv, Ca):
+        """reference :107-114"""
+        if self.fused_tail and Cv.is_cuda and Cv.shape[-1] <= 512:
+            return FusionTailFn.apply(Cv, Ca, 1, *self._tail_params())
+        Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
+        Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
+        return GateFn.apply(Cv, Ca, self.a_v_constant)
 
     def _memory_att(self, att, C, mem, mask, norm, kv_cache):
         """30 caption positions against a 256- / 800-long memory: the K/V projections are folded into the query side
@@ -191,12 +199,13 @@ def fusion_pair(fw, fm, C, Av, Va, masks):
     """Both fusion stacks (reference :523,528: same layers, different weights, same inputs) layer by layer with every
     product of the two stacks in one launch -- see functional.PairMemAttnFn.  Same arithmetic as BMFusion.forward on each
     stack; returns (worker features, manager features)."""
-    from ..functional import PairGateFn, PairMemAttnFn, PairRowFn, PairSelfAttnFn
+    from ..functional import FusionTailFn, PairGateFn, PairMemAttnFn, PairRowFn, PairSelfAttnFn
     C2 = torch.stack([C, C])                                     # (2, B, L, d_caps): stack 0 = worker, 1 = manager
     if '_pair' in masks:                                         # (the trainer builds the doubled masks with the single ones)
         cm2, am2, vm2 = masks['_pair']
     else:
         cm2, am2, vm2 = (torch.cat([masks[k], masks[k]]) for k in ('C_mask', 'A_mask', 'V_mask'))
+    fused_tail = BMFusionLayer.fused_tail and C.shape[-1] <= 512
     for lw, lm in zip(fw.decoder.layers, fm.decoder.layers):
         H = lw.self_att.H
         p = lw.self_att.dout_p if lw.training else 0.0
@@ -212,13 +221,18 @@ def fusion_pair(fw, fm, C, Av, Va, masks):
         with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
             Ca2 = PairMemAttnFn.apply(C2, Av, am2, H, p, *_att_params(lw.enc_att_A, lw.res_layer_enc_att_A.norm),
                                       *_att_params(lm.enc_att_A, lm.res_layer_enc_att_A.norm))
-            Ca2 = PairRowFn.apply(Ca2, lw.normCA.weight, lw.normCA.bias, lm.normCA.weight, lm.normCA.bias)
+            if not fused_tail:
+                Ca2 = PairRowFn.apply(Ca2, lw.normCA.weight, lw.normCA.bias, lm.normCA.weight, lm.normCA.bias)
         Cv2 = PairMemAttnFn.apply(C2, Va, vm2, H, p, *_att_params(lw.enc_att_V, lw.res_layer_enc_att_V.norm),
                                   *_att_params(lm.enc_att_V, lm.res_layer_enc_att_V.norm))
-        Cv2 = PairRowFn.apply(Cv2, lw.normCV.weight, lw.normCV.bias, lm.normCV.weight, lm.normCV.bias)
+        if not fused_tail:
+            Cv2 = PairRowFn.apply(Cv2, lw.normCV.weight, lw.normCV.bias, lm.normCV.weight, lm.normCV.bias)
         if side is not None:
             main.wait_stream(side)
-        C2 = PairGateFn.apply(Cv2, Ca2, lw.a_v_constant, lm.a_v_constant)
+        if fused_tail:       # both stacks' normCA + normCV + gate: one launch (it was six)
+            C2 = FusionTailFn.apply(Cv2, Ca2, 2, *lw._tail_params(), *lm._tail_params())
+        else:
+            C2 = PairGateFn.apply(Cv2, Ca2, lw.a_v_constant, lm.a_v_constant)
     return C2[0], C2[1]
 
 

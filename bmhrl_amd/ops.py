@@ -219,6 +219,32 @@ def gate_bwd(dout, cv, ca, a_v, dcv, dca, da_v, rows, D):
                                           dca.data_ptr(), _p(da_v), rows, D, stream()), "bmhrl_gate_bwd")
 
 
+def _tail_groups(groups, grads=None):
+    arr = (_lib.FusionTailParams * len(groups))()
+    for i, (g, a) in enumerate(zip(groups, arr)):
+        a.gamma_ca, a.beta_ca, a.gamma_cv, a.beta_cv, a.a_v = (t.data_ptr() for t in g)
+        if grads is not None:
+            a.dgamma_ca, a.dbeta_ca, a.dgamma_cv, a.dbeta_cv, a.da_v = (_p(t) for t in grads[i])
+    return arr
+
+
+def fusion_tail_fwd(ca, cv, groups, rows_per_group, D, out, stats):
+    """out = g * LN_CV(cv) + (1 - g) * LN_CA(ca); groups: list (1 or 2) of (gamma_ca, beta_ca, gamma_cv, beta_cv, a_v)"""
+    _need_cuda(ca, cv, out, stats)
+    arr = _tail_groups(groups)
+    _lib.check(_lib.load().bmhrl_fusion_tail_fwd(ca.data_ptr(), cv.data_ptr(), C.cast(arr, C.c_void_p), len(groups), rows_per_group, D,
+                                                 out.data_ptr(), stats.data_ptr(), stream()), "bmhrl_fusion_tail_fwd")
+
+
+def fusion_tail_bwd(dout, ca, cv, stats, groups, grads, rows_per_group, D, dca, dcv):
+    """grads: per group (dgamma_ca, dbeta_ca, dgamma_cv, dbeta_cv, da_v), zeroed fp32 tensors or None"""
+    _need_cuda(dout, ca, cv, stats, dca, dcv)
+    arr = _tail_groups(groups, grads)
+    _lib.check(_lib.load().bmhrl_fusion_tail_bwd(dout.data_ptr(), ca.data_ptr(), cv.data_ptr(), stats.data_ptr(), C.cast(arr, C.c_void_p),
+                                                 len(groups), rows_per_group, D, dca.data_ptr(), dcv.data_ptr(), stream()),
+               "bmhrl_fusion_tail_bwd")
+
+
 def expand_goals_index(seg, src, B, L):
     _lib.check(_lib.load().bmhrl_expand_goals_index(seg.data_ptr(), src.data_ptr(), B, L, stream()), "bmhrl_expand_goals_index")
 

@@ -221,6 +221,21 @@ int bmhrl_gate_fwd(const float* cv, const float* ca, const float* a_v, float* ou
 int bmhrl_gate_bwd(const float* dout, const float* cv, const float* ca, const float* a_v, float* dcv, float* dca,
                    float* da_v /* atomic += */, int64_t rows, int32_t D, bmhrl_stream_t stream);
 
+/* The tail of a BMFusionLayer in one launch (model/bm_hrl_agent.py:107-114): out = g * normCV(cv) + (1 - g) * normCA(ca),
+ * g = sigmoid(clamp(a_v, -2, 2)); rows are n_groups (1 or 2) groups of rows_per_group rows, group i with its own parameters
+ * (the worker and the manager stack advance together).  stats: (4, rows) fp32 out = mean / rstd of ca, mean / rstd of cv.
+ * bwd: dca / dcv (rows, D); the parameter gradients are ADDED (fp32 atomics) into the group's d* pointers (NULL: skipped),
+ * which the caller zeroes.  D <= 512. */
+typedef struct bmhrl_fusion_tail_params {
+  const float* gamma_ca; const float* beta_ca; const float* gamma_cv; const float* beta_cv; const float* a_v;
+  float* dgamma_ca; float* dbeta_ca; float* dgamma_cv; float* dbeta_cv; float* da_v;          /* backward only */
+} bmhrl_fusion_tail_params;
+int bmhrl_fusion_tail_fwd(const float* ca, const float* cv, const bmhrl_fusion_tail_params* groups, int32_t n_groups,
+                          int64_t rows_per_group, int32_t D, float* out, float* stats, bmhrl_stream_t stream);
+int bmhrl_fusion_tail_bwd(const float* dout, const float* ca, const float* cv, const float* stats,
+                          const bmhrl_fusion_tail_params* groups, int32_t n_groups, int64_t rows_per_group, int32_t D,
+                          float* dca, float* dcv, bmhrl_stream_t stream);
+
 /* Manager.expand_goals (K8), model/bm_hrl_agent.py:415-429: src[row] = row of goals_in copied to (b,l), or -1 = zero.
  * bmhrl_expand_goals_index builds the (B*L) int32 source map from the segment labels with the reference's
  * row-transition quirks; fwd is a gather, bwd a scatter-add. */

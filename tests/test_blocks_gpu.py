@@ -420,3 +420,37 @@ def test_pair_self_attention_equals_two_single_calls(B, L, dq, D, H):
                 continue
             tol = 5e-3 if n in ("bq", "bv") else 1e-4                # bias sums are taken after the bf16 rounding of dQ|dK|dV here
             assert err(u.grad, v.grad) < tol, (tag, n, err(u.grad, v.grad))
+
+
+def test_fusion_tail_one_launch_equals_norms_and_gate(dev):
+    """FusionTailFn (normCA + normCV + gate in one launch, one or two parameter groups) against torch autograd of the
+    reference's op chain (model/bm_hrl_agent.py:107-114), incl. a_v outside the clamp (no gradient) and both groups."""
+    from bmhrl_amd.functional import FusionTailFn
+    g = torch.Generator().manual_seed(12)
+    for D, B, L in ((300, 4, 30), (20, 3, 7), (384, 2, 5)):
+        cv = leaf(2, B, L, D, g=g, dev=dev)
+        ca = leaf(2, B, L, D, g=g, dev=dev)
+        params = []
+        for a0 in (0.3, 2.5):                       # the second group's gate is saturated by the clamp
+            params += [leaf(D, g=g, dev=dev), leaf(D, scale=0.1, g=g, dev=dev), leaf(D, g=g, dev=dev), leaf(D, scale=0.1, g=g, dev=dev),
+                       torch.tensor([a0], device=dev, requires_grad=True)]
+        dout = torch.randn(2, B, L, D, generator=g).to(dev)
+        out = FusionTailFn.apply(cv, ca, 2, *params)
+        out.backward(dout)
+        got = [t.grad.clone() for t in [cv, ca] + params]
+        for t in [cv, ca] + params:
+            t.grad = None
+        refs = []
+        for i in range(2):
+            wca, bca, wcv, bcv, a = params[5 * i:5 * i + 5]
+            gate = torch.sigmoid(torch.clamp(a, -2.0, 2.0))
+            refs.append(gate * F.layer_norm(cv[i], (D,), wcv, bcv, 1e-5) + (1 - gate) * F.layer_norm(ca[i], (D,), wca, bca, 1e-5))
+        ref = torch.stack(refs)
+        ref.backward(dout)
+        assert rel(out, ref) < 1e-5
+        for aa, t in zip(got, [cv, ca] + params):
+            assert rel(aa, t.grad, floor=1e-4) < 2e-4, (D, tuple(t.shape))
+        assert float(params[9].grad.abs().max()) == 0.0 and float(got[2 + 9].abs().max()) == 0.0
+        # one group == the same call on one stack
+        one = FusionTailFn.apply(cv[0].detach(), ca[0].detach(), 1, *[t.detach() for t in params[:5]])
+        assert torch.equal(one, out[0].detach())
