@@ -158,7 +158,7 @@ def attention_roofline(dev, B, H, Tv, Ta, iters=50):
     long_seq = long_shapes()
 
     traffic = None   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
-    tj = os.path.join(ROOT, "profiles", "r02_attn_traffic.json")
+    tj = os.path.join(ROOT, "profiles", "r03_attn_traffic.json")
     if os.path.exists(tj):
         t = json.load(open(tj))
         if t.get("shape") == {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk}:
