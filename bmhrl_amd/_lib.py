@@ -83,6 +83,7 @@ PROTOTYPES = {
     "bmhrl_scatter_add_rows": [ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_log_softmax": [ptr, i64, i64, i32, ptr],
     "bmhrl_smooth_kl_fwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, i32, ptr],
+    "bmhrl_smooth_kl_full": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i64, i32, ptr],
     "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
     "bmhrl_token_loss_reduce": [ptr, ptr, i64, i64, ptr, f32, ptr, ptr, ptr],
     "bmhrl_log_softmax_bwd": [ptr, ptr, i64, ptr, i64, i64, i32, ptr],

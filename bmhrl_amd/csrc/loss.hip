@@ -158,6 +158,24 @@ __global__ void smooth_kl_fwd_kernel(const float* __restrict__ logp, long ld, co
   row_loss[row] = loss;
 }
 
+// The unreduced (rows, V) divergence itself -- what the reference's criteria return (loss/label_smoothing.py:32,
+// loss/biased_kl.py:52) -- for callers that look at single entries (analyze_bmhrl_div); the training path only ever sums it.
+__global__ void smooth_kl_full_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
+                                      const int64_t* __restrict__ btrg, const float* __restrict__ score,
+                                      const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
+                                      float* __restrict__ out, long rows, int V) {
+  const long row = blockIdx.x;
+  const float* lp = logp + row * ld;
+  __shared__ RowTarget sT;
+  if (threadIdx.x == 0) sT = make_target(lp, trg, btrg, score, n_row, smoothing, pad, zero_pad_rows, row, rows, V, nullptr);
+  __syncthreads();
+  const RowTarget T = sT;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) {
+    const float d = T.at(c);
+    out[row * V + c] = xlogx(d) - d * lp[c];
+  }
+}
+
 __global__ void smooth_kl_bwd_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
                                      const int64_t* __restrict__ btrg, const float* __restrict__ score,
                                      const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
@@ -366,6 +384,16 @@ extern "C" int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t*
   BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
   hipLaunchKernelGGL(smooth_kl_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
                      score, n_row, smoothing, pad_idx, zero_pad_rows, row_loss, amp_out, (long)rows, V);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_smooth_kl_full(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg, const float* score,
+                                    const float* n_row, float smoothing, int32_t pad_idx, int32_t zero_pad_rows, float* out,
+                                    int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logp && trg && out && rows > 0 && V > 2);
+  BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
+  hipLaunchKernelGGL(smooth_kl_full_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg, score,
+                     n_row, smoothing, pad_idx, zero_pad_rows, out, (long)rows, V);
   return hip_status(hipGetLastError());
 }
 

@@ -31,6 +31,17 @@ class BiasedKL(nn.Module):
         rows, amp = ManagerKLFn.apply(pred, trg, biased_trg, score, n_seg, segments, float(self.ls), int(self.pad_idx))
         return rows.unsqueeze(-1), amp.view(trg.shape)
 
+    def unreduced(self, pred, trg, biased_trg, biased_offset):
+        """the (B*S, V) tensor the reference's forward returns (loss/biased_kl.py:52) for a GIVEN amplitude; no gradient."""
+        B, S, V = pred.shape
+        with torch.no_grad():
+            p = torch.gather(torch.exp(pred), 2, biased_trg.unsqueeze(-1)).squeeze(-1)
+            score = (biased_offset.detach().float() / p.clamp_min(1e-30)).contiguous().view(-1)
+            out = torch.empty(B * S, V, device=pred.device)
+            ops.smooth_kl_full(pred.detach().contiguous(), V, trg.contiguous().view(-1), biased_trg.contiguous().view(-1), score,
+                               torch.ones_like(score), float(self.ls), int(self.pad_idx), -1, out, B * S, V)
+        return out
+
     def forward(self, pred, trg, biased_trg, biased_offset, segments=None):
         # amp = clamp(offset * p(a) * n, 0, 1) with offset' = offset / p(a), n = 1 reproduces a given amplitude;
         # the gradient then treats the amplitude as constant only if it saturates -- use biased_kl_from_score

@@ -18,3 +18,14 @@ class LabelSmoothing(nn.Module):
     def forward(self, pred, target):  # pred (B, S, V) log-probs, target (B, S)
         rows, _ = SmoothKLFn.apply(pred, target, None, None, None, float(self.smoothing), int(self.pad_idx))
         return rows.unsqueeze(-1)
+
+    def unreduced(self, pred, target):
+        """the (B*S, V) tensor the reference's forward returns (loss/label_smoothing.py:32), for callers that look at single
+        entries; no gradient (training differentiates the row sums)."""
+        import torch
+        from .. import ops
+        B, S, V = pred.shape
+        out = torch.empty(B * S, V, device=pred.device)
+        ops.smooth_kl_full(pred.detach().contiguous(), V, target.contiguous().view(-1), None, None, None, float(self.smoothing),
+                           int(self.pad_idx), -1, out, B * S, V)
+        return out

@@ -269,6 +269,13 @@ def smooth_kl_fwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, z
                                                stream()), "bmhrl_smooth_kl_fwd")
 
 
+def smooth_kl_full(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, out, rows, V):
+    """the unreduced (rows, V) divergence of LabelSmoothing / BiasedKL (no gradient: the differentiable form is the row sums)"""
+    _need_cuda(logp, out)
+    _lib.check(_lib.load().bmhrl_smooth_kl_full(logp.data_ptr(), ld, trg.data_ptr(), _p(biased_trg), _p(score), _p(n_row), smoothing,
+                                                pad_idx, zero_pad_rows, out.data_ptr(), rows, V, stream()), "bmhrl_smooth_kl_full")
+
+
 def smooth_kl_bwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, g_bf16, ldg,
                   g_f32, rows, V, wrt_logits=True):
     _lib.check(_lib.load().bmhrl_smooth_kl_bwd(logp.data_ptr(), ld, trg.data_ptr(), _p(biased_trg), _p(score), _p(n_row),

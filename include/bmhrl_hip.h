@@ -262,6 +262,10 @@ int bmhrl_smooth_kl_fwd(const float* logp, int64_t ld, const int64_t* trg, const
                         const float* score, const float* n_row, float smoothing, int32_t pad_idx,
                         int32_t zero_pad_rows, float* row_loss, float* amp_out, int64_t rows, int32_t V,
                         bmhrl_stream_t stream);
+/* the unreduced divergence itself, (rows, V) fp32 -- the reference criteria's return value (callers that inspect entries) */
+int bmhrl_smooth_kl_full(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg, const float* score,
+                         const float* n_row, float smoothing, int32_t pad_idx, int32_t zero_pad_rows, float* out,
+                         int64_t rows, int32_t V, bmhrl_stream_t stream);
 int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
                         const float* score, const float* n_row, float smoothing, int32_t pad_idx,
                         int32_t zero_pad_rows, const float* loss_scale /* device scalar */, int32_t wrt_logits,

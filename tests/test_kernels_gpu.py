@@ -616,3 +616,26 @@ def test_token_loss_node_equals_sum_over_n_tokens(dev, golden):
     x = logits.clone().requires_grad_(True)
     loss = TokenLossFn.apply(torch.log_softmax(x, -1), trg, None, None, None, 0.7, 1, 1.0, None)
     assert rel_err(loss, ref.detach()) < 1e-5
+
+
+def test_criteria_unreduced_form_equals_the_reference_outputs(dev, golden):
+    """LabelSmoothing.unreduced / BiasedKL.unreduced return what the reference's forward returns -- the (B*S, V) divergence
+    itself (loss/label_smoothing.py:32, loss/biased_kl.py:52) -- checked against the reference's own outputs (kat.npz: the
+    SURVEY appendix A4 cases incl. the `idx.sum() > 0` guard; losses.npz: random case with padded rows)."""
+    from bmhrl_amd.loss.biased_kl import BiasedKL
+    from bmhrl_amd.loss.label_smoothing import LabelSmoothing
+    T = lambda a: torch.from_numpy(a).to(dev)
+    k = golden("kat")
+    lp = T(k["a4_lp"])
+    ls, bkl = LabelSmoothing(0.7, 1), BiasedKL(0.7, 1)
+    assert rel_err(ls.unreduced(lp, torch.tensor([[2, 4, 1], [5, 3, 2]], device=dev)), T(k["a4_ls"])) < 1e-5
+    assert rel_err(ls.unreduced(lp, torch.tensor([[1, 4, 2], [5, 3, 2]], device=dev)), T(k["a4_ls_guard"])) < 1e-5
+    got = bkl.unreduced(lp, torch.tensor([[2, 4, 1], [5, 3, 2]], device=dev), torch.tensor([[2, 0, 3], [1, 3, 4]], device=dev),
+                        torch.tensor([[.5, .25, 1.], [.8, 0., .1]], device=dev))
+    assert rel_err(got, T(k["a4_bkl"])) < 1e-5
+    g = golden("losses")
+    lp = torch.log_softmax(T(g["logits"]), -1)
+    assert rel_err(ls.unreduced(lp, T(g["trg"])), T(g["ls"])) < 1e-5
+    assert rel_err(bkl.unreduced(lp, T(g["trg"]), T(g["sampled"]), T(g["bkl_raw_amp"])), T(g["bkl_raw"])) < 1e-5
+    # and the row sums the training path uses are the sums of exactly these rows
+    assert rel_err(ls(lp, T(g["trg"])).view(-1), T(g["ls"]).sum(-1)) < 1e-5
