@@ -730,8 +730,9 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
         neg_m = -max_for_exp();
         thr_raw = (m_run + RESCALE_THR) / c_log2;
       }
-      // the loads issued at the top are read as K fragments in the NEXT iteration's O^T phase (NS = 4 stages within the DS
-      // immediate's reach): they have had the whole iteration to land
+      // the loads issued at the top are read as K fragments in the NEXT iteration's O^T phase: everything must have landed
+      // (they have had the whole iteration).  Deeper rings (NS = 5, 6: a split's stage is 8 KiB, up to 7 fit the DS immediate)
+      // that keep this iteration's pieces in flight across the barrier were measured SLOWER: loop 16.8-17.0 k vs 15.9 k cycles
       if constexpr (BMHRL_ABL & 1) return;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();

@@ -279,7 +279,10 @@ class SegmentCritic(nn.Module):
             return self.lin(self.relu2(h))
 
     wavefront = True       # False: one GEMM + L step launches per layer (the first native form; kept for A/B and tests)
-    wave_chunk = int(os.environ.get("BMHRL_WAVE_CHUNK", "3"))         # time steps a layer trails the one below: W_ih is read once per chunk (ops.rnn_wavefront)
+    # time steps a layer trails the one below: W_ih is read once per chunk (ops.rnn_wavefront).  r03 re-measured the step at
+    # chunk 1 / 2 / 3 / 5 on one box: 5.634 / 5.637 / 5.65 / 5.651 ms -- the chunk machinery no longer pays; default 1 (the
+    # plain wavefront, no projection scratch), the chunked form stays selectable and tested
+    wave_chunk = int(os.environ.get("BMHRL_WAVE_CHUNK", "1"))
 
     def score_and_labels(self, emb, threshold):
         """HIP path, fp32.  Returns (score (B, L, 1), labels (B, L) int32 = sigmoid(score) > threshold).
