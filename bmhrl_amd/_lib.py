@@ -65,6 +65,8 @@ PROTOTYPES = {
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_layernorm_bwd_ws": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr, i64, ptr],
+    "bmhrl_layernorm_fwd_groups": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, i32, ptr],
+    "bmhrl_layernorm_bwd_groups": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, i32, ptr],
     "bmhrl_add_posenc": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, f32, u64, ptr, ptr],
     "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
@@ -74,6 +76,8 @@ PROTOTYPES = {
     "bmhrl_cast_colsum_bf16_groups": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, i64, i64, ptr],
     "bmhrl_cast_segments": [ptr, i32, i32, ptr],
     "bmhrl_colsum_bf16": [ptr, i64, ptr, i32, i64, i32, ptr],
+    "bmhrl_colsum_bf16_groups": [ptr, i64, ptr, i64, i32, i32, i64, ptr],
+    "bmhrl_cast_bf16_copies": [ptr, i64, ptr, i64, i64, i32, i32, i64, ptr],
     "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_gate_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_fusion_tail_fwd": [ptr, ptr, ptr, i32, i64, i32, ptr, ptr, ptr],
@@ -84,7 +88,7 @@ PROTOTYPES = {
     "bmhrl_log_softmax": [ptr, i64, i64, i32, ptr],
     "bmhrl_smooth_kl_fwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, i32, ptr],
     "bmhrl_smooth_kl_full": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i64, i32, ptr],
-    "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
+    "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
     "bmhrl_token_loss_reduce": [ptr, ptr, i64, i64, ptr, f32, ptr, ptr, ptr],
     "bmhrl_log_softmax_bwd": [ptr, ptr, i64, ptr, i64, i64, i32, ptr],
     "bmhrl_smooth_kl_amp_grad": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i64, i32, ptr],
@@ -97,6 +101,7 @@ PROTOTYPES = {
     "bmhrl_critic_head": [ptr, ptr, ptr, f32, ptr, ptr, i64, i32, ptr],
     "bmhrl_adam_step": [ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
     "bmhrl_make_masks": [ptr, i64, ptr, i64, ptr, i32, i32, i32, i32, i64, i32, ptr, ptr, ptr, ptr],
+    "bmhrl_batch_head": [ptr, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, i64, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "bmhrl_adam_segments": [ptr, i32, i32, ptr, ptr, ptr, ptr, f32, f32, f32, f32, f32, i32, ptr, f32, ptr],
 }
 

@@ -53,6 +53,14 @@ __global__ void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __re
                                   bf16_t* __restrict__ yb, long ldy, float* __restrict__ yf, float* __restrict__ mean,
                                   float* __restrict__ rstd, long rows, int D) {
   static_assert(RPW == 1 || NV == 1, "several rows per wave only for rows that fit one 4-column group per lane");
+  if (blockIdx.y) {                     // group blockIdx.y of a grouped launch: `rows` rows of its own, its own gamma / beta
+    const long go = (long)blockIdx.y * rows;
+    x += go * D; gamma += blockIdx.y * D; beta += blockIdx.y * D;
+    if (yb) yb += go * ldy;
+    if (yf) yf += go * D;
+    if (mean) mean += go;
+    if (rstd) rstd += go;
+  }
   constexpr int LPR = 64 / RPW;
   const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR;
   const long row = ((long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * RPW + sub;
@@ -179,6 +187,13 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
                                   const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
                                   const float* __restrict__ dx_add, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   long rows, int D, int rows_per_wave, float* __restrict__ part) {
+  if (blockIdx.y) {                     // grouped launch (atomic form only): see ln_fwd_vec_kernel
+    const long go = (long)blockIdx.y * rows;
+    dy += go * D; x += go * D; dx += go * D; gamma += blockIdx.y * D; mean += go; rstd += go;
+    if (dx_add) dx_add += go * D;
+    if (dgamma) dgamma += blockIdx.y * D;
+    if (dbeta) dbeta += blockIdx.y * D;
+  }
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   const long r0 = wave_id * rows_per_wave;
@@ -349,6 +364,19 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* 
   }
 }
 
+// the same cast written `copies` times, copy c at y + c * copy_stride (the paired fusion stacks address the encoder memory as 2 B
+// samples: functional.StepScratch.memo_bf16)
+__global__ void cast_bf16_copies_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows, int cols,
+                                        int copies, long copy_stride) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % cols;
+    const long r = i / cols;
+    const bf16_t v = (bf16_t)x[r * ldx + c];
+    for (int k = 0; k < copies; ++k) y[k * copy_stride + r * ldy + c] = v;
+  }
+}
+
 // Split operand: x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  Three column blocks of width `part` at y: block 0 = hi,
 // block lo_slot (1 or 2) = lo, the remaining block = hi again.  An activation laid out [hi | hi | lo] against a weight laid out
 // [hi | lo | hi] gives x_hi W_hi + x_hi W_lo + x_lo W_hi in ONE GEMM with K = 3 part: the product to ~16 mantissa bits (the
@@ -476,8 +504,10 @@ __global__ void cast_colsum_kernel(const float* __restrict__ x, long ldx, bf16_t
 // db[n] (+)= sum_m dY[m][n]: a block covers 512 columns x `rows_per_block` rows; thread = (column group of 8 bf16 =
 // one 16-byte load, row lane 0..3); grid.y splits the rows; one atomic per column per block.
 __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ dY, long ld, float* __restrict__ db, long rows, int cols,
-                                   int rows_per_block) {
+                                   int rows_per_block, long db_stride) {
   __shared__ float red[4][512];
+  dY += (long)blockIdx.z * rows * ld;            // group blockIdx.z: `rows` rows of its own, its own sums
+  db += (long)blockIdx.z * db_stride;
   const int cg = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 512 + cg * 8;
   const long r0 = (long)blockIdx.y * rows_per_block;
@@ -838,6 +868,42 @@ __global__ void make_masks_kernel(const float* __restrict__ rgb, long ld_rgb, co
   }
 }
 
+// the same masks from captions[:, :-1] of a (B, L + 1) caption batch, plus the shifted copies the step works on and the
+// step's device counters (one thread)
+__global__ void batch_head_kernel(const float* __restrict__ rgb, long ld_rgb, const float* __restrict__ audio, long ld_aud,
+                                  const int64_t* __restrict__ cap, long ld_cap, int B, int Tv, int Ta, int L, int64_t pad,
+                                  int copies, uint8_t* __restrict__ vm, uint8_t* __restrict__ am, uint8_t* __restrict__ cm,
+                                  int64_t* __restrict__ trg_in, int64_t* __restrict__ trg_y, int64_t* bump64, int32_t* bump32_a,
+                                  int32_t* bump32_b) {
+  const long nv = (long)B * Tv, na = (long)B * Ta, nc = (long)B * L * L, nt = (long)B * L;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bump64) *bump64 += 1;
+    if (bump32_a) *bump32_a += 1;
+    if (bump32_b) *bump32_b += 1;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv + na + nc + nt; i += (long)gridDim.x * blockDim.x) {
+    uint8_t v;
+    uint8_t* dst;
+    long n, j;
+    if (i < nv) { j = i; v = rgb[j * ld_rgb] != 0.f; dst = vm; n = nv; }
+    else if (i < nv + na) { j = i - nv; v = audio[j * ld_aud] != 0.f; dst = am; n = na; }
+    else if (i < nv + na + nc) {
+      j = i - nv - na;
+      const long b = j / ((long)L * L), r = j - b * L * L;
+      const int qi = (int)(r / L), kj = (int)(r - (long)qi * L);
+      v = (cap[b * ld_cap + kj] != pad) && kj <= qi;
+      dst = cm; n = nc;
+    } else {
+      j = i - nv - na - nc;
+      const long b = j / L, l = j - b * L;
+      trg_in[j] = cap[b * ld_cap + l];
+      trg_y[j] = cap[b * ld_cap + l + 1];
+      continue;
+    }
+    for (int c = 0; c < copies; ++c) dst[c * n + j] = v;
+  }
+}
+
 inline unsigned grid_for(long total, int block = 256, int cap = 2048) {
   long g = (total + block - 1) / block;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -964,6 +1030,62 @@ extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const flo
   return hip_status(hipGetLastError());
 }
 
+// `groups` independent LayerNorms of rows_per_group rows each, laid out back to back (x, y, mean, rstd: group-major; gamma,
+// beta, dgamma, dbeta: (groups, D)) -- the worker and the manager half of a paired fusion block -- as ONE launch
+extern "C" int bmhrl_layernorm_fwd_groups(const float* x, const float* gamma, const float* beta, void* y_bf16, int64_t ldy,
+                                          float* y_f32, float* mean, float* rstd, int64_t rows_per_group, int32_t D,
+                                          int32_t groups, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32) && rows_per_group > 0 && D > 0 && groups >= 1 && groups <= 65535);
+  const int64_t rows = rows_per_group;
+  const bool vec = D % 4 == 0 && D <= 1024 && ldy % 4 == 0 && D > 128 &&
+                   ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_f32) & 15) == 0) && (((uintptr_t)y_bf16 & 7) == 0);
+  if (!vec || groups == 1) {
+    for (int g = 0; g < groups; ++g) {
+      const int rc = bmhrl_layernorm_fwd(x + g * rows * D, gamma + (long)g * D, beta + (long)g * D,
+                                         y_bf16 ? (char*)y_bf16 + 2 * g * rows * ldy : nullptr, ldy, y_f32 ? y_f32 + g * rows * D : nullptr,
+                                         mean ? mean + g * rows : nullptr, rstd ? rstd + g * rows : nullptr, rows, D, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), (unsigned)groups), block(256);
+  const int nv = (D + 255) / 256;
+#define LN_FWDG(NV_) hipLaunchKernelGGL((ln_fwd_vec_kernel<NV_, 1>), grid, block, 0, S_(stream), x, gamma, beta, (bf16_t*)y_bf16, \
+                                        (long)ldy, y_f32, mean, rstd, (long)rows, D)
+  if (nv <= 1) LN_FWDG(1); else if (nv <= 2) LN_FWDG(2); else LN_FWDG(4);
+#undef LN_FWDG
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_layernorm_bwd_groups(const float* dy, const float* x, const float* gamma, const float* mean,
+                                          const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                                          int64_t rows_per_group, int32_t D, int32_t groups, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows_per_group > 0 && D > 0 && D <= 64 * LN_MAXC && groups >= 1 &&
+                  groups <= 65535);
+  const int64_t rows = rows_per_group;
+  int rv; long blocks;
+  ln_bwd_ws_plan(rows, D, &rv, &blocks);
+  static const long atomic_max = getenv("BMHRL_LN_ATOMIC_BLOCKS") ? atol(getenv("BMHRL_LN_ATOMIC_BLOCKS")) : 128;
+  const bool vec = D % 4 == 0 && D <= 1024 &&
+                   ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0);
+  if (!vec || groups == 1 || blocks > atomic_max) {
+    for (int g = 0; g < groups; ++g) {
+      const int rc = bmhrl_layernorm_bwd(dy + g * rows * D, x + g * rows * D, gamma + (long)g * D, mean + g * rows, rstd + g * rows,
+                                         dx + g * rows * D, dx_add ? dx_add + g * rows * D : nullptr,
+                                         dgamma ? dgamma + (long)g * D : nullptr, dbeta ? dbeta + (long)g * D : nullptr, rows, D, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  dim3 gridv((unsigned)blocks, (unsigned)groups), block(256);
+  const int nv = (D + 255) / 256;
+#define LN_BWDG(NV_) hipLaunchKernelGGL((ln_bwd_vec_kernel<NV_, false>), gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
+                                        dx_add, dgamma, dbeta, (long)rows, D, rv, (float*)nullptr)
+  if (nv <= 1) LN_BWDG(1); else if (nv <= 2) LN_BWDG(2); else LN_BWDG(4);
+#undef LN_BWDG
+  return hip_status(hipGetLastError());
+}
+
 extern "C" int bmhrl_add_posenc(const float* a, const float* b, const float* pe, float* out, void* out_bf16, int64_t ldob,
                                 int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                 bmhrl_stream_t stream) {
@@ -998,6 +1120,14 @@ extern "C" int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy
   BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y,
                      (long)ldy, (long)rows, cols, scale, dropout_p, seed, seed_dev);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_cast_bf16_copies(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols,
+                                      int32_t copies, int64_t copy_stride, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldy >= cols && ldx >= cols && copies >= 1 && (copies == 1 || copy_stride >= rows * ldy));
+  hipLaunchKernelGGL(cast_bf16_copies_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y,
+                     (long)ldy, (long)rows, cols, copies, (long)copy_stride);
   return hip_status(hipGetLastError());
 }
 
@@ -1060,7 +1190,21 @@ extern "C" int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t 
   int rpb = (int)((rows * col_blocks + 511) / 512);      // aim at ~512 blocks in total
   if (rpb < 16) rpb = 16;
   dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), block(256);
-  hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows, cols, rpb);
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows, cols, rpb, 0l);
+  return hip_status(hipGetLastError());
+}
+
+// the same for `groups` row groups laid out back to back, sums of group g ADDED at db + g * db_stride: one launch
+extern "C" int bmhrl_colsum_bf16_groups(const void* dY, int64_t ld, float* db, int64_t rows_per_group, int32_t cols,
+                                        int32_t groups, int64_t db_stride, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dY && db && rows_per_group > 0 && cols > 0 && groups >= 1 && groups <= 65535);
+  BMHRL_CHECK_ARG(ld % 8 == 0 && ((uintptr_t)dY & 15) == 0);
+  const int col_blocks = (cols + 511) / 512;
+  int rpb = (int)((rows_per_group * groups * col_blocks + 511) / 512);
+  if (rpb < 16) rpb = 16;
+  dim3 grid((unsigned)col_blocks, (unsigned)((rows_per_group + rpb - 1) / rpb), (unsigned)groups), block(256);
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows_per_group, cols, rpb,
+                     (long)db_stride);
   return hip_status(hipGetLastError());
 }
 
@@ -1174,10 +1318,25 @@ extern "C" int bmhrl_make_masks(const float* rgb, int64_t ld_rgb, const float* a
   return hip_status(hipGetLastError());
 }
 
+extern "C" int bmhrl_batch_head(const float* rgb, int64_t ld_rgb, const float* audio, int64_t ld_aud, const int64_t* captions,
+                                int64_t ld_cap, int32_t B, int32_t Tv, int32_t Ta, int32_t L, int64_t pad_idx, int32_t copies,
+                                uint8_t* v_mask, uint8_t* a_mask, uint8_t* c_mask, int64_t* trg_in, int64_t* trg_y,
+                                int64_t* bump64, int32_t* bump32_a, int32_t* bump32_b, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(rgb && audio && captions && v_mask && a_mask && c_mask && trg_in && trg_y);
+  BMHRL_CHECK_ARG(B > 0 && Tv > 0 && Ta > 0 && L > 0 && copies >= 1 && ld_cap >= L + 1);
+  const long total = (long)B * (Tv + Ta + (long)L * L + L);
+  hipLaunchKernelGGL(batch_head_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), rgb, (long)ld_rgb, audio, (long)ld_aud,
+                     captions, (long)ld_cap, B, Tv, Ta, L, pad_idx, copies, v_mask, a_mask, c_mask, trg_in, trg_y, bump64, bump32_a,
+                     bump32_b);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 // 2: bmhrl_gemm_desc.colsum, bmhrl_cast_colsum_bf16, bmhrl_cast_segments
 // 3: bmhrl_layernorm_bwd_ws (+ _workspace), bmhrl_rnn_wavefront / bmhrl_rnn_layer; attention outputs 16-byte aligned, ldo % 8 == 0
 // 7: bmhrl_adam_segments   8: bmhrl_gemm_desc.colsum_sb1 / bias_sb1, fp16 attention entry points   9: bmhrl_make_masks
 // 10: bmhrl_softmax_bwd_rows, bmhrl_cast_split3_bf16 (+ split shadows in the segment tables), DSCORE honours the mask,
 //     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce, bmhrl_fusion_tail_fwd / _bwd
-extern "C" int bmhrl_hip_abi_version(void) { return 10; }
+// 11: bmhrl_batch_head, bmhrl_smooth_kl_bwd loss_scale2, bmhrl_layernorm_fwd_groups / _bwd_groups, bmhrl_colsum_bf16_groups,
+//     bmhrl_cast_bf16_copies
+extern "C" int bmhrl_hip_abi_version(void) { return 11; }

@@ -179,13 +179,13 @@ __global__ void smooth_kl_full_kernel(const float* __restrict__ logp, long ld, c
 __global__ void smooth_kl_bwd_kernel(const float* __restrict__ logp, long ld, const int64_t* __restrict__ trg,
                                      const int64_t* __restrict__ btrg, const float* __restrict__ score,
                                      const float* __restrict__ n_row, float smoothing, int pad, int zero_pad_rows,
-                                     const float* __restrict__ loss_scale, int wrt_logits, bf16_t* __restrict__ gb,
-                                     long ldg, float* __restrict__ gf, long rows, int V) {
+                                     const float* __restrict__ loss_scale, const float* __restrict__ loss_scale2,
+                                     int wrt_logits, bf16_t* __restrict__ gb, long ldg, float* __restrict__ gf, long rows, int V) {
   const long row = blockIdx.x;
   const float* lp = logp + row * ld;
   float raw = 0.f;
   const RowTarget T = make_target(lp, trg, btrg, score, n_row, smoothing, pad, zero_pad_rows, row, rows, V, &raw);
-  const float scale = loss_scale[0];
+  const float scale = loss_scale2 ? loss_scale[0] * loss_scale2[0] : loss_scale[0];
   // d rowloss / d logp_v = -dist'_v, plus the amplitude path on column a:
   //   d rowloss/d amp = keep * [ (log d'_a + 1 - logp_a) - (t != pad) * (log d'_t + 1 - logp_t) ],  d amp/d logp_a = raw
   float extra_a = 0.f;
@@ -407,12 +407,13 @@ extern "C" int bmhrl_token_loss_reduce(const float* row_loss, const int64_t* trg
 
 extern "C" int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
                                    const float* score, const float* n_row, float smoothing, int32_t pad_idx,
-                                   int32_t zero_pad_rows, const float* loss_scale, int32_t wrt_logits, void* dlogits_bf16,
-                                   int64_t ldg, float* dlogits_f32, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+                                   int32_t zero_pad_rows, const float* loss_scale, const float* loss_scale2, int32_t wrt_logits,
+                                   void* dlogits_bf16, int64_t ldg, float* dlogits_f32, int64_t rows, int32_t V,
+                                   bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(logp && trg && loss_scale && (dlogits_bf16 || dlogits_f32) && rows > 0 && V > 2);
   BMHRL_CHECK_ARG(!biased_trg || (score && n_row));
   hipLaunchKernelGGL(smooth_kl_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, S_(stream), logp, (long)ld, trg, biased_trg,
-                     score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, wrt_logits, (bf16_t*)dlogits_bf16,
+                     score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, loss_scale2, wrt_logits, (bf16_t*)dlogits_bf16,
                      (long)ldg, dlogits_f32, (long)rows, V);
   return hip_status(hipGetLastError());
 }

@@ -215,21 +215,32 @@ class StepScratch:
         self.spill = 0
         self.cursor = {}
         self.memo = {}
+        self._zeroing = None
 
     # (the buffers live in the bound state)
     arena = property(lambda self: self.state.arena, lambda self, v: setattr(self.state, "arena", v))
     need = property(lambda self: self.state.need, lambda self, v: setattr(self.state, "need", v))
     pool = property(lambda self: self.state.pool)
 
-    def begin_step(self, device, state: Optional[ScratchState] = None):
+    def begin_step(self, device, state: Optional[ScratchState] = None, zero_stream=None):
+        """zero_stream: run the arena's fill there (forked from the current stream) instead of in line -- only the backward
+        pass touches the arena, so the fill (200 MB at the reference widths) overlaps the forward; the caller joins it with
+        join_zero() before backward (f32() joins by itself should something ask for arena memory earlier)."""
         device = torch.device(device)
         if device.type != "cuda":
             return
         self.state = state if state is not None else self.default_state
+        self._zeroing = None
         if self.arena is None or self.arena.device != device or self.arena.numel() < self.need:
             self.arena = torch.zeros(self.need, device=device) if self.need else None
         elif self.off_of_last_step():
-            self.arena[:self.off_of_last_step()].zero_()
+            if zero_stream is not None:
+                zero_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(zero_stream):
+                    self.arena[:self.off_of_last_step()].zero_()
+                self._zeroing = zero_stream
+            else:
+                self.arena[:self.off_of_last_step()].zero_()
         self.off = self.spill = 0
         self.cursor = {}
         self.memo = {}
@@ -239,7 +250,14 @@ class StepScratch:
         """elements of the bound state's arena a step may have written (its own high-water mark)"""
         return min(self.state.need, self.arena.numel()) if self.arena is not None else 0
 
+    def join_zero(self):
+        """the current stream waits for the arena's fill (begin_step(zero_stream=...)); call on the stream the step runs on"""
+        if self._zeroing is not None:
+            torch.cuda.current_stream().wait_stream(self._zeroing)
+            self._zeroing = None
+
     def end_step(self):
+        self.join_zero()
         self.need = max(self.need, self.off + self.spill)
         self.armed = False
 
@@ -249,6 +267,8 @@ class StepScratch:
             n *= d
         n4 = (n + 3) & ~3
         a = self.arena
+        if self._zeroing is not None:
+            self.join_zero()
         if not self.armed or a is None or a.device != device or self.off + n4 > a.numel():
             if self.armed:
                 self.spill += n4
@@ -267,9 +287,7 @@ class StepScratch:
             if hit is not None and hit[0]() is t:
                 return hit[1]
         buf = self.bf16(copies * rows, cols, t.device)
-        tc = t.contiguous()
-        for c in range(copies):
-            ops.cast_bf16(tc, cols, buf[c * rows:], buf.shape[1], rows, cols)
+        ops.cast_bf16_copies(t.contiguous(), cols, buf, buf.shape[1], rows, cols, copies, rows * buf.shape[1])
         if self.armed:
             self.memo[key] = (weakref.ref(t), buf)
         return buf
@@ -806,8 +824,7 @@ class PairMemAttnFn(torch.autograd.Function):
         xb = SCRATCH.bf16(2 * R, dq, dev)
         mean = torch.empty(2 * R, device=dev)
         rstd = torch.empty(2 * R, device=dev)
-        for i in range(2):
-            ops.layernorm_fwd(x2[i], ln_w[i].detach(), ln_b[i].detach(), xb[i * R:], ldx, None, mean[i * R:], rstd[i * R:], R, dq)
+        ops.layernorm_fwd_groups(x2, SHADOWS.bias(*ln_w), SHADOWS.bias(*ln_b), xb, ldx, None, mean, rstd, R, dq, 2)
         s_attn, s_res = SEEDS.next(), SEEDS.next()
         w_q, w_k, w_v, w_o = SHADOWS.weight(*wq), SHADOWS.weight(*wk), SHADOWS.weight(*wv), SHADOWS.weight(*wo)
         Qb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
@@ -920,10 +937,9 @@ class PairMemAttnFn(torch.autograd.Function):
             grad_mem(dxn, True)                         # the keys / values are LN(x) too
         dx2 = torch.empty(2, B, L, dq, device=dev)
         dln = []
-        for i in range(2):
-            dlnw, dlnb = SCRATCH.f32(dq, device=dev), SCRATCH.f32(dq, device=dev)
-            ops.layernorm_bwd(dxn[i * R:], x2[i], ln_w[i], mean[i * R:], rstd[i * R:], dx2[i], dy2[i], dlnw, dlnb, R, dq)
-            dln.append((dlnw, dlnb))
+        dlnw2, dlnb2 = SCRATCH.f32(2 * dq, device=dev), SCRATCH.f32(2 * dq, device=dev)
+        ops.layernorm_bwd_groups(dxn, x2, SHADOWS.bias(*ln_w), mean, rstd, dx2, dy2, dlnw2, dlnb2, R, dq, 2)
+        dln = [(dlnw2[i * dq:(i + 1) * dq], dlnb2[i * dq:(i + 1) * dq]) for i in range(2)]
         out = []
         for i in range(2):
             g = (dln[i][0], dln[i][1], dwq[i * D:(i + 1) * D], dbq[i * D:(i + 1) * D], dwk[i * D:(i + 1) * D], dbk[i * D:(i + 1) * D],
@@ -952,8 +968,7 @@ class PairSelfAttnFn(torch.autograd.Function):
         xb = SCRATCH.bf16(2 * R, dq, dev)
         mean = torch.empty(2 * R, device=dev)
         rstd = torch.empty(2 * R, device=dev)
-        for i in range(2):
-            ops.layernorm_fwd(x2[i], ln_w[i].detach(), ln_b[i].detach(), xb[i * R:], ldx, None, mean[i * R:], rstd[i * R:], R, dq)
+        ops.layernorm_fwd_groups(x2, SHADOWS.bias(*ln_w), SHADOWS.bias(*ln_b), xb, ldx, None, mean, rstd, R, dq, 2)
         s_attn, s_res = SEEDS.next(), SEEDS.next()
         w_qkv = SHADOWS.weight(wq[0], wk[0], wv[0], wq[1], wk[1], wv[1])
         b_qkv = SHADOWS.bias(bq[0], bk[0], bv[0], bq[1], bk[1], bv[1])
@@ -1000,8 +1015,7 @@ class PairSelfAttnFn(torch.autograd.Function):
         _attn_core_bwd(dOb, Ob, ("mat", P), QKV, 0, 3 * D, QKV, D, 3 * D, QKV, 2 * D, 3 * D, dQKV, 0, 3 * D, dQKV, D, 3 * D,
                        dQKV, 2 * D, 3 * D, m8, msb, msq, B2, H, L, L, dk, p_drop)
         db = SCRATCH.f32(2 * 3 * D, device=dev)           # bias gradients [q | k | v] of each half: column sums of its rows
-        for i in range(2):
-            ops.colsum_bf16(dQKV, 3 * D, db, True, R, 3 * D, dy_off=i * R * 3 * D, db_off=i * 3 * D)
+        ops.colsum_bf16_groups(dQKV, 3 * D, db, R, 3 * D, 2, 3 * D)
         w_qkv = SHADOWS.weight(wq[0], wk[0], wv[0], wq[1], wk[1], wv[1])
         dw = SCRATCH.f32(2 * 3 * D, dq, device=dev)
         ops.gemm(dQKV, xb, 3 * D, dq, R, lda=3 * D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
@@ -1011,9 +1025,10 @@ class PairSelfAttnFn(torch.autograd.Function):
                  b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq))
         dx2 = torch.empty(2, B, L, dq, device=dev)
         out = []
+        dlnw2, dlnb2 = SCRATCH.f32(2 * dq, device=dev), SCRATCH.f32(2 * dq, device=dev)
+        ops.layernorm_bwd_groups(dxn, x2, SHADOWS.bias(*ln_w), mean, rstd, dx2, dy2, dlnw2, dlnb2, R, dq, 2)
         for i in range(2):
-            dlnw, dlnb = SCRATCH.f32(dq, device=dev), SCRATCH.f32(dq, device=dev)
-            ops.layernorm_bwd(dxn[i * R:], x2[i], ln_w[i], mean[i * R:], rstd[i * R:], dx2[i], dy2[i], dlnw, dlnb, R, dq)
+            dlnw, dlnb = dlnw2[i * dq:(i + 1) * dq], dlnb2[i * dq:(i + 1) * dq]
             w0, b0 = i * 3 * D, i * 3 * D
             g = (dlnw, dlnb, dw[w0:w0 + D], db[b0:b0 + D], dw[w0 + D:w0 + 2 * D], db[b0 + D:b0 + 2 * D],
                  dw[w0 + 2 * D:w0 + 3 * D], db[b0 + 2 * D:b0 + 3 * D], dwo[i * dq:(i + 1) * dq], dbo[i * dq:(i + 1) * dq])
@@ -1385,6 +1400,12 @@ class ExpandGoalsFn(torch.autograd.Function):
         return dx, None
 
 
+# WorkerHeadFn <-> TokenLossFn hand-over: addresses (+ version) of log-prob tensors a WorkerHeadFn produced, and the bf16
+# d logits a TokenLossFn(sole_consumer=True) computed in place of the fp32 d log-probs it returns (keyed by that tensor)
+_HEAD_LOGP = {}
+_GRAD_TWIN = {}
+
+
 class WorkerHeadFn(torch.autograd.Function):
     """log_softmax( Linear_{(d_in+d_goal) -> V}( cat[x, goal_completion] ) ) -- model/bm_hrl_agent.py:483-484,463-466.
     The concatenation only exists as the bf16 GEMM operand; logits / log-probs stay fp32.  The log-probs are what north_star
@@ -1409,6 +1430,9 @@ class WorkerHeadFn(torch.autograd.Function):
         ops.log_softmax_(logp, V, rows, V)
         ctx.save_for_backward(xb, w, logp)
         ctx.cfg = (B, L, d1, d2, V)
+        if len(_HEAD_LOGP) > 64:
+            _HEAD_LOGP.clear()
+        _HEAD_LOGP[logp.data_ptr()] = (logp._version, tuple(logp.shape))
         return logp
 
     @staticmethod
@@ -1418,8 +1442,12 @@ class WorkerHeadFn(torch.autograd.Function):
         dev = dlogp.device
         rows, K = B * L, d1 + d2
         need = ctx.needs_input_grad
-        gb = SCRATCH.bf16(rows, V, dev)
-        ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
+        _HEAD_LOGP.pop(logp.data_ptr(), None)
+        gb = _GRAD_TWIN.pop(dlogp.data_ptr(), None)       # TokenLossFn(sole_consumer=True): d logits, already bf16
+        _GRAD_TWIN.clear()
+        if gb is None:
+            gb = SCRATCH.bf16(rows, V, dev)
+            ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
         wb = SHADOWS.weight_split3(w)                           # block 0 of both operands = the plain bf16 copies
         dcat = torch.empty(rows, K, device=dev) if (need[0] or need[1]) else None
         dw, db = _linear_bwd(gb, gb.shape[1], rows, V, xb, xb.shape[1], K, wb, need_dw=need[2], need_db=need[3],
@@ -1498,10 +1526,14 @@ class TokenLossFn(torch.autograd.Function):
     a one-block reduce, and the backward hands its scalar straight to the gradient kernel (no (rows, V) multiply pass)."""
 
     @staticmethod
-    def forward(ctx, logp, trg, biased_trg, score, n_row, smoothing, pad_idx, factor, weight):
+    def forward(ctx, logp, trg, biased_trg, score, n_row, smoothing, pad_idx, factor, weight, sole_consumer=False):
+        """sole_consumer: the caller guarantees that nothing else differentiates through `logp` -- when logp is the output of
+        WorkerHeadFn its backward then takes the bf16 d logits straight from this node's gradient kernel (log-softmax
+        backward folded in: no fp32 (rows, V) gradient, no log_softmax_bwd launch)."""
         B, S, V = logp.shape
         rows = B * S
         dev = logp.device
+        ctx.twin = bool(sole_consumer) and logp.is_contiguous() and _HEAD_LOGP.get(logp.data_ptr()) == (logp._version, tuple(logp.shape))
         logp = logp.contiguous()
         trg = trg.contiguous().view(-1)
         bt = biased_trg.contiguous().view(-1) if biased_trg is not None else None
@@ -1522,9 +1554,17 @@ class TokenLossFn(torch.autograd.Function):
         logp, trg, bt, sc, nr, out = ctx.saved_tensors
         rows = B * S
         g = torch.empty(rows, V, device=logp.device)
-        scale = out[1:2] * dloss.reshape(1)                  # (one element)
-        ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, scale, None, 0, g, rows, V, wrt_logits=False)
-        return g.view(B, S, V), None, None, None, None, None, None, None, None
+        dl = dloss.reshape(1)                                # (one element; multiplied in by the kernel)
+        if ctx.twin:
+            # g stays unwritten: WorkerHeadFn.backward finds the bf16 d logits under g's address
+            gb = SCRATCH.bf16(rows, V, logp.device)
+            ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], gb, gb.shape[1], None, rows, V,
+                              wrt_logits=True, loss_scale2=dl)
+            _GRAD_TWIN[g.data_ptr()] = gb
+        else:
+            ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], None, 0, g, rows, V, wrt_logits=False,
+                              loss_scale2=dl)
+        return g.view(B, S, V), None, None, None, None, None, None, None, None, None
 
 
 class ManagerKLFn(torch.autograd.Function):

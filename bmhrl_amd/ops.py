@@ -136,6 +136,26 @@ def layernorm_fwd(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows, D):
                                                _p(mean), _p(rstd), rows, D, stream()), "bmhrl_layernorm_fwd")
 
 
+def layernorm_fwd_groups(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows_per_group, D, groups):
+    """`groups` LayerNorms of rows_per_group rows each, back to back, in one launch; gamma / beta are (groups, D)"""
+    _need_cuda(x)
+    if gamma.numel() != groups * D or beta.numel() != groups * D:
+        raise RuntimeError("layernorm_fwd_groups: gamma / beta must hold one row of D per group")
+    _lib.check(_lib.load().bmhrl_layernorm_fwd_groups(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y_bf16), ldy, _p(y_f32),
+                                                      _p(mean), _p(rstd), rows_per_group, D, groups, stream()),
+               "bmhrl_layernorm_fwd_groups")
+
+
+def layernorm_bwd_groups(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows_per_group, D, groups):
+    """backward of layernorm_fwd_groups; dgamma / dbeta (groups, D) are ADDED to (zero them first)"""
+    _need_cuda(x)
+    if gamma.numel() != groups * D or any(t is not None and t.numel() != groups * D for t in (dgamma, dbeta)):
+        raise RuntimeError("layernorm_bwd_groups: gamma / dgamma / dbeta must hold one row of D per group")
+    _lib.check(_lib.load().bmhrl_layernorm_bwd_groups(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                      dx.data_ptr(), _p(dx_add), _p(dgamma), _p(dbeta), rows_per_group, D, groups,
+                                                      stream()), "bmhrl_layernorm_bwd_groups")
+
+
 def layernorm_bwd_workspace(rows, D) -> int:
     """fp32 elements of the scratch the two-stage column sums of layernorm_bwd go through (uninitialised is fine)."""
     return int(_lib.load().bmhrl_layernorm_bwd_workspace(rows, D))
@@ -209,6 +229,19 @@ def colsum_bf16(dY, ld, db, accumulate, rows, cols, dy_off=0, db_off=0):
                                              rows, cols, stream()), "bmhrl_colsum_bf16")
 
 
+def colsum_bf16_groups(dY, ld, db, rows_per_group, cols, groups, db_stride):
+    """db[g * db_stride + n] += sum over the rows of group g of dY[., n] (bf16 (groups * rows_per_group, ld)); one launch"""
+    _lib.check(_lib.load().bmhrl_colsum_bf16_groups(dY.data_ptr(), ld, db.data_ptr(), rows_per_group, cols, groups, db_stride,
+                                                    stream()), "bmhrl_colsum_bf16_groups")
+
+
+def cast_bf16_copies(x, ldx, y, ldy, rows, cols, copies, copy_stride):
+    """y[c * copy_stride + r * ldy + n] = bf16(x[r * ldx + n]) for every copy c; one launch"""
+    _need_cuda(x, y)
+    _lib.check(_lib.load().bmhrl_cast_bf16_copies(x.data_ptr(), ldx, y.data_ptr(), ldy, rows, cols, copies, copy_stride, stream()),
+               "bmhrl_cast_bf16_copies")
+
+
 def gate_fwd(cv, ca, a_v, out, out_bf16, ldob, rows, D):
     _lib.check(_lib.load().bmhrl_gate_fwd(cv.data_ptr(), ca.data_ptr(), a_v.data_ptr(), out.data_ptr(), _p(out_bf16), ldob,
                                           rows, D, stream()), "bmhrl_gate_fwd")
@@ -277,10 +310,11 @@ def smooth_kl_full(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, 
 
 
 def smooth_kl_bwd(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, loss_scale, g_bf16, ldg,
-                  g_f32, rows, V, wrt_logits=True):
+                  g_f32, rows, V, wrt_logits=True, loss_scale2=None):
+    """loss_scale (and the optional loss_scale2, multiplied in) are one-element device tensors"""
     _lib.check(_lib.load().bmhrl_smooth_kl_bwd(logp.data_ptr(), ld, trg.data_ptr(), _p(biased_trg), _p(score), _p(n_row),
-                                               smoothing, pad_idx, zero_pad_rows, loss_scale.data_ptr(), int(wrt_logits), _p(g_bf16), ldg,
-                                               _p(g_f32), rows, V, stream()), "bmhrl_smooth_kl_bwd")
+                                               smoothing, pad_idx, zero_pad_rows, loss_scale.data_ptr(), _p(loss_scale2),
+                                               int(wrt_logits), _p(g_bf16), ldg, _p(g_f32), rows, V, stream()), "bmhrl_smooth_kl_bwd")
 
 
 def smooth_kl_amp_grad(logp, ld, trg, biased_trg, score, n_row, smoothing, pad_idx, zero_pad_rows, out, rows, V):
@@ -383,3 +417,30 @@ def make_masks(rgb, audio, trg, pad_idx, copies=1):
                                             Ta, L, pad_idx, copies, vm.data_ptr(), am.data_ptr(), cm.data_ptr(), stream()),
                "bmhrl_make_masks")
     return vm, am, cm
+
+
+def batch_head(rgb, audio, captions, pad_idx, copies=1, bump64=None, bump32=()):
+    """Head of a training step, one launch: captions (B, L + 1) -> (trg_in, trg_y) = (captions[:, :-1], captions[:, 1:])
+    as contiguous tensors, make_masks() of trg_in, and `bump64` (int64 device word: the seed) / up to two int32 device
+    counters in `bump32` (Adam steps) advanced by one.  Returns (vm, am, cm, trg_in, trg_y)."""
+    _need_cuda(rgb, audio, captions)
+    B, Tv = rgb.shape[:2]
+    Ta, L = audio.shape[1], captions.shape[1] - 1
+    if rgb.stride(2) != 1 or rgb.stride(0) != Tv * rgb.stride(1) or audio.stride(2) != 1 or audio.stride(0) != Ta * audio.stride(1):
+        raise RuntimeError("batch_head: feature stacks must be (B, T, D) with contiguous rows")
+    if captions.dtype != torch.int64 or captions.stride(1) != 1 or L < 1:
+        raise RuntimeError("batch_head: captions must be (B, L + 1) int64 with contiguous rows")
+    if len(bump32) > 2 or any(t.dtype != torch.int32 for t in bump32) or (bump64 is not None and bump64.dtype != torch.int64):
+        raise RuntimeError("batch_head: counters are one int64 word and at most two int32 words")
+    dev = rgb.device
+    vm = torch.empty(copies * B, 1, Tv, dtype=torch.bool, device=dev)
+    am = torch.empty(copies * B, 1, Ta, dtype=torch.bool, device=dev)
+    cm = torch.empty(copies * B, L, L, dtype=torch.bool, device=dev)
+    trg_in = torch.empty(B, L, dtype=torch.int64, device=dev)
+    trg_y = torch.empty(B, L, dtype=torch.int64, device=dev)
+    b32 = list(bump32) + [None, None]
+    _lib.check(_lib.load().bmhrl_batch_head(rgb.data_ptr(), rgb.stride(1), audio.data_ptr(), audio.stride(1), captions.data_ptr(),
+                                            captions.stride(0), B, Tv, Ta, L, pad_idx, copies, vm.data_ptr(), am.data_ptr(),
+                                            cm.data_ptr(), trg_in.data_ptr(), trg_y.data_ptr(), _p(bump64), _p(b32[0]), _p(b32[1]),
+                                            stream()), "bmhrl_batch_head")
+    return vm, am, cm, trg_in, trg_y

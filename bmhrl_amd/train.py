@@ -240,14 +240,15 @@ class FlatAdam:
                 return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
         return None
 
-    def step_part(self, part: int, grad_scale: float = 1.0):
+    def step_part(self, part: int, grad_scale: float = 1.0, dev_step_advanced: bool = False):
         """the update of bucket `part` alone (its gradients are complete; later buckets are still in backward).  Needs the
         plan of a previous full step(); the step counters advance with bucket 0."""
         b1, b2 = self.betas
         if part == 0:
             self.step_count += 1
             self.generation += 1
-            self.step_dev.add_(1)
+            if not dev_step_advanced:
+                self.step_dev.add_(1)
         table, n_seg, n_blk = self._part_plans[part]
         if n_seg:
             ops.adam_segments(table, n_seg, n_blk, self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, b1, b2, self.eps,
@@ -256,12 +257,15 @@ class FlatAdam:
             for kind, key in self._seg_plan[1][3]:
                 SHADOWS.mark_stale(kind, key)
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, dev_step_advanced: bool = False):
+        """dev_step_advanced: the device step counter was already advanced for this step (ops.batch_head does it in the
+        step's first launch)"""
         self.step_count += 1
         self.generation += 1
         b1, b2 = self.betas
         if self.flat.is_cuda:
-            self.step_dev.add_(1)
+            if not dev_step_advanced:
+                self.step_dev.add_(1)
             plan = self._segment_plan() if self.fused_shadows else None
             if plan is None:
                 ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.n, self.lr, b1, b2, self.eps,
@@ -394,20 +398,36 @@ class CaptionTrainer:
         SEEDS.dev = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------ one step, eager
-    def _forward_loss(self, fs, trg_in, trg_y, rl=None):
-        if fs["rgb"].is_cuda:
-            # every mask of the step, and their doubled copies for the paired fusion stacks, in one launch
-            B = trg_in.shape[0]
-            vm2, am2, cm2 = ops.make_masks(fs["rgb"], fs["audio"], trg_in, self.pad_idx, copies=2)
-            masks = {"V_mask": vm2[:B], "A_mask": am2[:B], "C_mask": cm2[:B], "_pair": (cm2, am2, vm2)}
-        else:
-            masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
+    def _head(self, fs, captions):
+        """The step's first launch (ops.batch_head): captions -> (trg_in, trg_y), every mask of the step with its doubled
+        copy for the paired fusion stacks, the seed word and the optimisers' device step counters advanced.  CPU tensors:
+        the plain form."""
+        if not captions.is_cuda:
+            SEEDS.dev.add_(1)
+            trg_in, trg_y = captions[:, :-1].contiguous(), captions[:, 1:].contiguous()
+            return trg_in, trg_y, make_masks(fs, trg_in, self.modality, self.pad_idx)
+        B = captions.shape[0]
+        counters = [self.opt.step_dev] + ([self.vopt.step_dev] if self.value_net is not None else [])
+        vm2, am2, cm2, trg_in, trg_y = ops.batch_head(fs["rgb"], fs["audio"], captions, self.pad_idx, copies=2, bump64=SEEDS.dev,
+                                                      bump32=counters)
+        return trg_in, trg_y, {"V_mask": vm2[:B], "A_mask": am2[:B], "C_mask": cm2[:B], "_pair": (cm2, am2, vm2)}
+
+    def _forward_loss(self, fs, trg_in, trg_y, rl=None, masks=None):
+        if masks is None:
+            if fs["rgb"].is_cuda:
+                # every mask of the step, and their doubled copies for the paired fusion stacks, in one launch
+                B = trg_in.shape[0]
+                vm2, am2, cm2 = ops.make_masks(fs["rgb"], fs["audio"], trg_in, self.pad_idx, copies=2)
+                masks = {"V_mask": vm2[:B], "A_mask": am2[:B], "C_mask": cm2[:B], "_pair": (cm2, am2, vm2)}
+            else:
+                masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
         pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
         if self.phase == "warmstart" and rl is None and pred.is_cuda:
-            # sum(LabelSmoothing) / n_tokens (x the rank's token weight) as one node: functional.TokenLossFn
+            # sum(LabelSmoothing) / n_tokens (x the rank's token weight) as one node: functional.TokenLossFn; the
+            # prediction has no other differentiated consumer here, so the head's backward takes d logits from that node
             w = self.loss_weight if self._world_scale() != 1.0 else None
             return TokenLossFn.apply(pred, trg_y, None, None, None, float(self.criterion.smoothing), int(self.criterion.pad_idx),
-                                     1.0, w), pred
+                                     1.0, w, True), pred
         loss_mask = trg_y != self.pad_idx
         n_tokens = loss_mask.sum()
         if self.phase != "warmstart":
@@ -454,30 +474,47 @@ class CaptionTrainer:
 
     def step(self, fs, captions, rl=None):
         """zero_grad -> forward -> loss -> backward -> (all-reduce) -> Adam.  Returns the loss (device scalar)."""
-        trg_in, trg_y = captions[:, :-1].contiguous(), captions[:, 1:].contiguous()
         self._sync_token_weight(captions)
         self.opt.zero_grad()
         if self.value_net is not None:
             self.vopt.zero_grad()
         SCRATCH.begin_step(self.device, self.scratch)
-        SEEDS.dev.add_(1)
+        trg_in, trg_y, masks = self._head(fs, captions)
         SHADOWS.refresh()
-        loss, _ = self._forward_loss(fs, trg_in, trg_y, rl)
-        loss.backward()
+        loss, _ = self._forward_loss(fs, trg_in, trg_y, rl, masks)
+        loss.backward(gradient=self._unit_grad(loss))
         self.opt.gather_grads()
         if self.value_net is not None:
             self.vopt.gather_grads()
         SCRATCH.end_step()
         scale = self.opt.all_reduce()
-        self.opt.step(scale)
+        adv = captions.is_cuda
+        self.opt.step(scale, dev_step_advanced=adv)
         if self.value_net is not None:
             self.vopt.all_reduce()
-            self.vopt.step(scale)
+            self.vopt.step(scale, dev_step_advanced=adv)
         return loss.detach()
+
+    def _unit_grad(self, loss):
+        """d loss / d loss as a constant kept for the trainer's lifetime (autograd otherwise fills a fresh one every step)"""
+        one = self.__dict__.get("_one")
+        if one is None or one.device != loss.device or one.dtype != loss.dtype:
+            one = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        return one
 
     # ------------------------------------------------------------------ whole-step HIP graph
     _warm_streams = {}
     _adam_streams = {}
+    _zero_streams = {}
+
+    def _zero_stream(self):
+        """side stream of the scratch arena's fill (StepScratch.begin_step); one per device and process"""
+        if not os.environ.get("BMHRL_ZERO_STREAM", "0") == "1":
+            return None
+        s = CaptionTrainer._zero_streams.get(self.device)
+        if s is None:
+            s = CaptionTrainer._zero_streams[self.device] = torch.cuda.Stream(device=self.device)
+        return s
 
     def capture(self, fs, captions, warmup: int = 3):
         """Capture step() for static shapes; afterwards replay(fs, captions) copies the inputs into the captured
@@ -503,6 +540,9 @@ class CaptionTrainer:
                         self._graph_body_phase(j)
                 self.opt.zero_grad()
                 SEEDS.dev.sub_(1)             # (the pass does not count as a step: dropout masks / samples continue as if it had not run)
+                self.opt.step_dev.sub_(1)     # (nor do the optimisers' device counters, which the step's first launch advanced)
+                if self.value_net is not None:
+                    self.vopt.step_dev.sub_(1)
             for _ in range(max(1, warmup)):   # at least one eager pass: lazily built tables / shadows must exist
                 self._sync_token_weight(self.static["captions"])
                 self._graph_body_a()
@@ -534,12 +574,12 @@ class CaptionTrainer:
                 for j in range(1, self.n_enc + 1):
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        self.opt.step_part(j - 1, 1.0)
+                        self.opt.step_part(j - 1, 1.0, dev_step_advanced=True)
                     self._graph_body_phase(j)
                 main.wait_stream(side)
-                self.opt.step_part(self.n_enc, 1.0)
+                self.opt.step_part(self.n_enc, 1.0, dev_step_advanced=True)
                 if self.value_net is not None:
-                    self.vopt.step(1.0)
+                    self.vopt.step(1.0, dev_step_advanced=True)
             elif alone:                       # no all-reduce to leave room for: the optimizer joins the same graph
                 self._graph_body_b(1.0)
         if alone:
@@ -579,19 +619,19 @@ class CaptionTrainer:
     def _graph_body_a(self):
         st = self.static
         cap = st["captions"]
-        trg_in, trg_y = cap[:, :-1].contiguous(), cap[:, 1:].contiguous()
         self.opt.zero_grad()
         if self.value_net is not None:
             self.vopt.zero_grad()
-        SCRATCH.begin_step(self.device, self.scratch)
-        SEEDS.dev.add_(1)
+        SCRATCH.begin_step(self.device, self.scratch, zero_stream=self._zero_stream())
+        trg_in, trg_y, masks = self._head(st, cap)
         if not self.opt.fused_shadows:
             SHADOWS.invalidate()
         for o in (self.opt, getattr(self, "vopt", None)):
             if o is not None:
                 o.mark_uncovered_stale()
         SHADOWS.refresh()                     # (fused_shadows: the Adam pass keeps the shadows current -- usually nothing to do)
-        loss, _ = self._forward_loss(st, trg_in, trg_y)
+        loss, _ = self._forward_loss(st, trg_in, trg_y, None, masks)
+        SCRATCH.join_zero()
         if self._split():
             # phase 0 of the backward: everything downstream of the encoder output (head, both fusion stacks, embedding)
             # (RL phases: the value head hangs off detached features -- its parameters are leaves of this first phase too; in
@@ -599,7 +639,8 @@ class CaptionTrainer:
             cut = [t for t in self._layer_out[self.n_enc - 1] if t.requires_grad]
             vparams = list(self.vopt.params) if self.value_net is not None else []
             leaves = self.early_params + vparams
-            outs = torch.autograd.grad(loss, leaves + cut, retain_graph=bool(cut), allow_unused=True)
+            outs = torch.autograd.grad(loss, leaves + cut, grad_outputs=self._unit_grad(loss), retain_graph=bool(cut),
+                                       allow_unused=True)
             for p, g in zip(leaves, outs):
                 p.grad = g
             self._cut = (cut, list(outs[len(leaves):]))
@@ -607,12 +648,13 @@ class CaptionTrainer:
             if self.value_net is not None:
                 self.vopt.gather_grads()
         else:
-            loss.backward()
+            loss.backward(gradient=self._unit_grad(loss))
             self.opt.gather_grads()
             if self.value_net is not None:
                 self.vopt.gather_grads()
             SCRATCH.end_step()
-        self.static_loss.copy_(loss.detach())
+        # the loss of the captured step lives in the graph's own pool: the tensor IS the static output (no copy launch)
+        self.static_loss = loss.detach()
 
     def _graph_body_phase(self, j: int):
         """phase j = 1..n_enc of the backward (split mode): encoder layer n_enc - j, from the gradients of its outputs
@@ -636,9 +678,9 @@ class CaptionTrainer:
             SCRATCH.end_step()
 
     def _graph_body_b(self, scale):
-        self.opt.step(scale)
+        self.opt.step(scale, dev_step_advanced=True)              # (the counters moved in the step's first launch: _head)
         if self.value_net is not None:
-            self.vopt.step(scale)
+            self.vopt.step(scale, dev_step_advanced=True)
 
     def replay(self, fs=None, captions=None):
         if fs is not None:

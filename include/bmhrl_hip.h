@@ -163,6 +163,16 @@ int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, 
                            float* dx, const float* dx_add, float* dgamma, float* dbeta, int64_t rows, int32_t D,
                            float* workspace, int64_t workspace_floats, bmhrl_stream_t stream);
 
+/* `groups` independent LayerNorms of rows_per_group rows each in one launch (the worker and the manager half of a paired
+ * fusion block, model/bm_hrl_agent.py:523,528): x, y, mean, rstd, dy, dx are group-major ((groups * rows_per_group, .)),
+ * gamma / beta / dgamma / dbeta are (groups, D).  Same arithmetic per row as bmhrl_layernorm_fwd / _bwd. */
+int bmhrl_layernorm_fwd_groups(const float* x, const float* gamma, const float* beta, void* y_bf16, int64_t ldy, float* y_f32,
+                               float* mean, float* rstd, int64_t rows_per_group, int32_t D, int32_t groups,
+                               bmhrl_stream_t stream);
+int bmhrl_layernorm_bwd_groups(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                               float* dx, const float* dx_add, float* dgamma, float* dbeta, int64_t rows_per_group, int32_t D,
+                               int32_t groups, bmhrl_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Feature add + positional encoding (K1): out = a (+ b) + PE[s]  (epoch_loops/captioning_bmrl_loops.py:498,
  * model/blocks.py:105-112).  pe is the precomputed fp32 table (S_max, D).  Optional bf16 copy and dropout.
@@ -214,6 +224,13 @@ int bmhrl_cast_segments(const int64_t* segments, int32_t n_segments, int32_t n_b
 /* db[n] (+)= sum_m dY[m][n]  (bias gradient of nn.Linear), dY bf16 */
 int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t accumulate, int64_t rows, int32_t cols,
                       bmhrl_stream_t stream);
+/* the same for `groups` row groups laid out back to back ((groups * rows_per_group, ld)); the sums of group g are ADDED at
+ * db + g * db_stride (zero them first).  One launch. */
+int bmhrl_colsum_bf16_groups(const void* dY, int64_t ld, float* db, int64_t rows_per_group, int32_t cols, int32_t groups,
+                             int64_t db_stride, bmhrl_stream_t stream);
+/* y[c] = bf16(x) for c in [0, copies): copy c starts copy_stride elements after copy c - 1 (no scale, no dropout) */
+int bmhrl_cast_bf16_copies(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols, int32_t copies,
+                           int64_t copy_stride, bmhrl_stream_t stream);
 
 /* Fusion gate (K7): out = g*Cv + (1-g)*Ca, g = sigmoid(clamp(a,-2,2)), model/bm_hrl_agent.py:111-114 */
 int bmhrl_gate_fwd(const float* cv, const float* ca, const float* a_v, float* out, void* out_bf16, int64_t ldob,
@@ -268,8 +285,10 @@ int bmhrl_smooth_kl_full(const float* logp, int64_t ld, const int64_t* trg, cons
                          int64_t rows, int32_t V, bmhrl_stream_t stream);
 int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const int64_t* biased_trg,
                         const float* score, const float* n_row, float smoothing, int32_t pad_idx,
-                        int32_t zero_pad_rows, const float* loss_scale /* device scalar */, int32_t wrt_logits,
-                        void* grad_bf16, int64_t ldg, float* grad_f32, int64_t rows, int32_t V, bmhrl_stream_t stream);
+                        int32_t zero_pad_rows, const float* loss_scale /* device scalar */,
+                        const float* loss_scale2 /* second device scalar multiplied in (the incoming d loss), or NULL */,
+                        int32_t wrt_logits, void* grad_bf16, int64_t ldg, float* grad_f32, int64_t rows, int32_t V,
+                        bmhrl_stream_t stream);
 /* The loops' reduction of the row sums: loss = weight * sum(row_loss) / (n_tokens * factor), n_tokens = #(trg != pad_idx)
  * (epoch_loops/captioning_bmrl_loops.py:1156-1158: factor 1; :829-833,846-862: factor 4/20); scale = weight / (n_tokens *
  * factor) is what bmhrl_smooth_kl_bwd takes as loss_scale.  weight: optional device scalar (data-parallel token weight). */
@@ -357,6 +376,16 @@ int bmhrl_adam_segments(const int64_t* segments, int32_t n_segments, int32_t n_b
 int bmhrl_make_masks(const float* rgb, int64_t ld_rgb, const float* audio, int64_t ld_aud, const int64_t* trg, int32_t B,
                      int32_t Tv, int32_t Ta, int32_t L, int64_t pad_idx, int32_t copies, uint8_t* v_mask, uint8_t* a_mask,
                      uint8_t* c_mask, bmhrl_stream_t stream);
+
+/* Head of a training step in one launch (epoch_loops/captioning_bmrl_loops.py:487-508 feature_getter: the input / target
+ * shift of the captions; model/masking.py:28-55: the masks built from the SHIFTED input): captions (B, L + 1) int64 with row
+ * stride ld_cap -> trg_in = captions[:, :-1], trg_y = captions[:, 1:] (contiguous (B, L)), the three masks of
+ * bmhrl_make_masks from trg_in, and the step's device counters advanced by one: bump64 (the dropout / sampling seed word)
+ * and bump32[0..1] (Adam step counters); each may be NULL. */
+int bmhrl_batch_head(const float* rgb, int64_t ld_rgb, const float* audio, int64_t ld_aud, const int64_t* captions,
+                     int64_t ld_cap, int32_t B, int32_t Tv, int32_t Ta, int32_t L, int64_t pad_idx, int32_t copies,
+                     uint8_t* v_mask, uint8_t* a_mask, uint8_t* c_mask, int64_t* trg_in, int64_t* trg_y, int64_t* bump64,
+                     int32_t* bump32_a, int32_t* bump32_b, bmhrl_stream_t stream);
 
 /* Library self-description: returns the gfx target the kernels were built for ("gfx950"). */
 const char* bmhrl_hip_arch(void);

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
                                     "bmhrl_attention_shared128_bwd_workspace", "bmhrl_attention_max_keys"} == set(syms)
     assert lib.bmhrl_layernorm_bwd_workspace(4096, 1024) == 256 * 2 * 1024      # 4 rows per wave, 4 waves per block: 256 blocks
     assert lib.bmhrl_hip_arch() == b"gfx950"
-    assert lib.bmhrl_hip_abi_version() == 10
+    assert lib.bmhrl_hip_abi_version() == 11
     assert lib.bmhrl_attention_max_keys() == 10112        # pure host query: the fused kernels' key limit
 
 

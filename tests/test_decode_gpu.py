@@ -41,8 +41,10 @@ def test_memoised_decode_equals_full_rerun():
     full = greedy_decode(agent, fs, 10, 2, -1, 1, "audio_video", memoise=False)
     torch.cuda.synchronize()
     t_full = time.perf_counter() - t0
-    t0 = time.perf_counter()
     memo, first_memo = greedy_decode(agent, fs, 10, 2, -1, 1, "audio_video", return_first=True, incremental=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()                 # (both forms timed on their second run: the first one builds shadows and pools)
+    memo = greedy_decode(agent, fs, 10, 2, -1, 1, "audio_video", incremental=False)
     torch.cuda.synchronize()
     t_memo = time.perf_counter() - t0
     assert torch.equal(full, memo)

@@ -593,6 +593,114 @@ def test_make_masks_kernel_equals_the_reference_functions(dev):
     assert not bool(ref["V_mask"].all()) and not bool(ref["C_mask"][:, -1].all())      # padding is present in the case
 
 
+@pytest.mark.parametrize("rows,D", [(480, 300), (37, 128), (64, 1024), (2100, 300)])
+def test_layernorm_groups_equal_one_launch_per_group(dev, rows, D):
+    """bmhrl_layernorm_fwd_groups / _bwd_groups (one launch for the worker and the manager half of a paired block) == the
+    single-group entry points on each half, bit for bit in the forward and in dx; column sums up to the order of the atomics"""
+    from bmhrl_amd import ops
+    torch.manual_seed(rows + D)
+    G = 2
+    x = torch.randn(G, rows, D, device=dev) * 2 + 0.3
+    gam, bet = torch.randn(G, D, device=dev), torch.randn(G, D, device=dev)
+    ld = (D + 7) & ~7
+    yb, yf = torch.zeros(G * rows, ld, dtype=torch.bfloat16, device=dev), torch.empty(G, rows, D, device=dev)
+    mean, rstd = torch.empty(G * rows, device=dev), torch.empty(G * rows, device=dev)
+    ops.layernorm_fwd_groups(x, gam, bet, yb, ld, yf, mean, rstd, rows, D, G)
+    yb1, yf1 = torch.zeros_like(yb), torch.empty_like(yf)
+    mean1, rstd1 = torch.empty_like(mean), torch.empty_like(rstd)
+    for g in range(G):
+        ops.layernorm_fwd(x[g], gam[g], bet[g], yb1[g * rows:], ld, yf1[g], mean1[g * rows:], rstd1[g * rows:], rows, D)
+    assert torch.equal(yb, yb1) and torch.equal(yf, yf1) and torch.equal(mean, mean1) and torch.equal(rstd, rstd1)
+    assert rel_err(yf, torch.nn.functional.layer_norm(x, (D,)) * gam[:, None] + bet[:, None]) < 1e-5
+    dy, add = torch.randn(G, rows, D, device=dev), torch.randn(G, rows, D, device=dev)
+    dx, dg, db = torch.empty_like(x), torch.zeros(G, D, device=dev), torch.zeros(G, D, device=dev)
+    ops.layernorm_bwd_groups(dy, x, gam, mean, rstd, dx, add, dg, db, rows, D, G)
+    dx1, dg1, db1 = torch.empty_like(x), torch.zeros(G, D, device=dev), torch.zeros(G, D, device=dev)
+    for g in range(G):
+        ops.layernorm_bwd(dy[g], x[g], gam[g], mean[g * rows:], rstd[g * rows:], dx1[g], add[g], dg1[g], db1[g], rows, D)
+    assert torch.equal(dx, dx1)
+    assert rel_err(dg, dg1) < 1e-5 and rel_err(db, db1) < 1e-5
+
+
+def test_grouped_colsum_and_copied_cast(dev):
+    """bmhrl_colsum_bf16_groups == bmhrl_colsum_bf16 per group; bmhrl_cast_bf16_copies == bmhrl_cast_bf16 per copy"""
+    from bmhrl_amd import ops
+    torch.manual_seed(9)
+    R, N, G = 480, 3072, 2
+    dY = torch.randn(G * R, N, device=dev).bfloat16()
+    db = torch.zeros(G * N + 8, device=dev)
+    ops.colsum_bf16_groups(dY, N, db, R, N, G, N)
+    ref = dY.float().view(G, R, N).sum(1).reshape(-1)
+    assert rel_err(db[:G * N], ref) < 1e-5 and float(db[G * N:].abs().max()) == 0.0
+    one = torch.zeros(N, device=dev)
+    ops.colsum_bf16(dY, N, one, True, R, N, dy_off=R * N)
+    assert rel_err(db[N:2 * N], one) < 1e-6
+    x = torch.randn(200, 300, device=dev)
+    ld = 304
+    y = torch.zeros(2 * 200, ld, dtype=torch.bfloat16, device=dev)
+    ops.cast_bf16_copies(x, 300, y, ld, 200, 300, 2, 200 * ld)
+    y1 = torch.zeros(200, ld, dtype=torch.bfloat16, device=dev)
+    ops.cast_bf16(x, 300, y1, ld, 200, 300)
+    assert torch.equal(y[:200], y1) and torch.equal(y[200:], y1) and float(y[:, 300:].float().abs().max()) == 0.0
+
+
+def test_batch_head_equals_shift_masks_and_counters(dev):
+    """bmhrl_batch_head == captions[:, :-1] / captions[:, 1:] + make_masks of the shifted input (single and doubled) + the three
+    device counters advanced by exactly one per launch"""
+    from bmhrl_amd import ops, synthetic as syn
+    from bmhrl_amd.model.masking import make_masks
+    b = syn.synthetic_batch(5, 37, 90, 11, 60, seed=4, min_len=3)
+    fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+    fs["audio"][1, 7, 0] = 0.0
+    cap = b["captions"].to(dev)
+    ref = make_masks(fs, cap[:, :-1], "audio_video", 1)
+    seed = torch.tensor([41], dtype=torch.int64, device=dev)
+    s1, s2 = torch.tensor([6], dtype=torch.int32, device=dev), torch.tensor([0], dtype=torch.int32, device=dev)
+    for copies in (1, 2):
+        vm, am, cm, trg_in, trg_y = ops.batch_head(fs["rgb"], fs["audio"], cap, 1, copies=copies, bump64=seed, bump32=[s1, s2])
+        assert torch.equal(trg_in, cap[:, :-1]) and torch.equal(trg_y, cap[:, 1:]) and trg_in.is_contiguous() and trg_y.is_contiguous()
+        for got, want in ((vm, ref["V_mask"]), (am, ref["A_mask"]), (cm, ref["C_mask"])):
+            assert got.dtype == torch.bool and torch.equal(got, torch.cat([want] * copies))
+    assert int(seed) == 43 and int(s1) == 8 and int(s2) == 2
+    ops.batch_head(fs["rgb"], fs["audio"], cap, 1)                      # counters are optional
+    assert int(seed) == 43
+    with pytest.raises(RuntimeError):
+        ops.batch_head(fs["rgb"], fs["audio"], cap.int(), 1)
+
+
+def test_head_takes_dlogits_from_the_token_loss_node(dev):
+    """TokenLossFn(sole_consumer=True) behind WorkerHeadFn: the head's backward uses the bf16 d logits the loss node's kernel
+    wrote (log-softmax backward folded in) -- same gradients as the two-launch path, and the plain path when the log-probs
+    did not come from a head or were not declared sole-consumer"""
+    from bmhrl_amd import functional as F
+    torch.manual_seed(5)
+    B, L, d1, d2, V = 3, 7, 40, 24, 333
+    x0, g0 = torch.randn(B, L, d1, device=dev), torch.randn(B, L, d2, device=dev)
+    w0, b0 = torch.randn(V, d1 + d2, device=dev) * 0.1, torch.randn(V, device=dev) * 0.1
+    trg = torch.randint(2, V, (B, L), device=dev)
+    trg[0, 5:] = 1
+    up = torch.tensor(2.5, device=dev)
+    res = []
+    for sole in (False, True):
+        x, gc, w, b = (t.clone().requires_grad_(True) for t in (x0, g0, w0, b0))
+        logp = F.WorkerHeadFn.apply(x, gc, w, b)
+        loss = F.TokenLossFn.apply(logp, trg, None, None, None, 0.7, 1, 1.0, None, sole)
+        loss.backward(gradient=up)
+        assert not F._GRAD_TWIN
+        res.append((loss.detach(), x.grad, gc.grad, w.grad, b.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, c in zip(res[0][1:], res[1][1:]):
+        assert rel_err(c, a) < 4e-3            # (one bf16 rounding of d logits instead of two)
+    # log-probs that no head produced: the flag changes nothing
+    lp = torch.log_softmax(torch.randn(B, L, V, device=dev), -1)
+    y = []
+    for sole in (False, True):
+        z = lp.clone().requires_grad_(True)
+        F.TokenLossFn.apply(z, trg, None, None, None, 0.7, 1, 1.0, None, sole).backward()
+        y.append(z.grad)
+    assert torch.equal(y[0], y[1]) and not F._GRAD_TWIN
+
+
 def test_token_loss_node_equals_sum_over_n_tokens(dev, golden):
     """functional.TokenLossFn (row sums -> one-block reduce -> scalar, gradient scaled inside the kernel) == the loops'
     torch.sum(criterion(pred, y)) / (n_tokens * factor) over SmoothKLFn, value and gradient; against the oracle too."""
