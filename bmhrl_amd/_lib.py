@@ -133,6 +133,8 @@ def load() -> C.CDLL:
     lib.bmhrl_attention_shared128_bwd_workspace.argtypes = [i32, i32, i32]
     lib.bmhrl_attention_shared128_bwd_workspace.restype = C.c_int64
     lib.bmhrl_attention_max_keys.restype = C.c_int
+    lib.bmhrl_gemm_splits.argtypes = [i32, i32, i32, i32]
+    lib.bmhrl_gemm_splits.restype = C.c_int
     lib.bmhrl_hip_arch.restype = C.c_char_p
     lib.bmhrl_hip_abi_version.restype = C.c_int
     _lib = lib

@@ -817,7 +817,60 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
   return hipGetLastError();
 }
 
+// Tile size and K split of a problem -- ONE function for the launcher and for bmhrl_gemm_splits (callers that hand a weight
+// gradient GEMM uninitialised memory must know for certain that it will not be accumulated into with atomics).
+struct TilePlan { bool big, mid; int splits; };
+TilePlan tile_plan(int M, int N, int K, int batch, bool can_split) {
+  TilePlan t;
+  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  const long small_tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+  // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight
+  // gradients dW = dY^T X.  Only plain fp32 outputs qualify and the caller must opt in (C zero-initialised).
+  int splits = 1;
+  static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
+  static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
+  bool big = force_tile ? force_tile >= 2 : big_tiles >= big_min;
+  // (128x128 tiles + K split for small outputs: re-measured slower than 64x64 tiles + K split since the deep-prefetch /
+  //  epilogue changes -- V dW 30 vs 23 us, A-out dW 25 vs 18 us; kept behind BMHRL_GEMM_BIGSPLIT=1 as a tuning aid)
+  static const int big_split = getenv("BMHRL_GEMM_BIGSPLIT") ? atoi(getenv("BMHRL_GEMM_BIGSPLIT")) : 0;
+  if (big_split && can_split && !force_tile && M >= 128 && N >= 128 && big_tiles <= 96 && K >= 1024) {
+    // weight gradients with a small output and a long reduction: 128x128 tiles (about 3x the rate of 64x64 ones),
+    // the chip is filled through the K split
+    const int ktiles = (K + BK - 1) / BK;
+    int s2 = (int)((256 + big_tiles - 1) / big_tiles);
+    if (s2 > ktiles / 4) s2 = ktiles / 4;
+    if (s2 >= 2) { big = true; splits = s2; }
+  }
+  if (splits == 1 && can_split && !big && small_tiles < 192) {
+    const int ktiles = (K + BK - 1) / BK;
+    splits = (int)((512 + small_tiles - 1) / small_tiles);
+    if (splits > ktiles / 4) splits = ktiles / 4;   // >= 256 of K per split
+    if (splits < 1) splits = 1;
+  }
+  // 128x128 tiles only when they still give every CU (256) a block; otherwise 64x64 tiles fill the chip better.
+  // (256 x 128 tiles, one workgroup of 4 waves x 128 x 64 per CU with 512 registers per wave -- 48 KiB of operands per k-step for
+  // twice the FLOPs of a square tile -- were built and measured SLOWER on every shape: 4096 x 3072 x 1024 48.5 vs 38.5 us,
+  // 8192^3 1025 vs 1097 TF/s: what two co-resident workgroups hide for each other outweighs the lower traffic per FLOP.)
+  // 128 x 64 tiles when 128 x 128 ones would give a CU at most one workgroup (the 4096 x 1024 projections of the video stream:
+  // 256 tiles): two workgroups per CU cover each other's waits -- 4096 x 1024 x 1024 19.3 -> 17.0 us, its dX 16.1 -> 13.7 us;
+  // with more columns (2048, 3072) the square tile's lower traffic per FLOP wins (26.5 vs 31.5 us).  Alone, that is: inside
+  // the captured step, where the audio branch runs next to these GEMMs, the step measured 6.06 - 6.23 ms with them against
+  // 5.95 ms without, so the option is off by default (BMHRL_GEMM_MIDMAX=256 turns it on, BMHRL_GEMM_TILE=3 forces it).
+  static const int mid_max = getenv("BMHRL_GEMM_MIDMAX") ? atoi(getenv("BMHRL_GEMM_MIDMAX")) : 0;
+  t.mid = force_tile ? force_tile == 3 : (big && splits == 1 && big_tiles <= mid_max);
+  t.big = big;
+  t.splits = splits;
+  return t;
+}
+
 }  // namespace
+
+// how many K splits bmhrl_gemm uses for a plain fp32 (M, N) = A^T-style product with allow_split_k set: 1 means every element
+// of C is written exactly once (C may be uninitialised), > 1 means fp32 atomics into a C that must be zero
+extern "C" int bmhrl_gemm_splits(int32_t M, int32_t N, int32_t K, int32_t batch) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return -1;
+  return tile_plan(M, N, K, batch, true).splits;
+}
 
 extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(d && d->A && d->B && (d->C || d->Cb));
@@ -864,45 +917,12 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   a.fast_pd = (d->epilogue == BMHRL_EPI_PROB && out_ok && d->rowvec2 && (!d->mask || d->mask_sm == 0) && !d->aux) ||
               (d->epilogue == BMHRL_EPI_DSCORE && out_ok && d->aux && al(d->aux, 16) && d->ldaux % 8 == 0 &&
                d->aux_sb1 % 8 == 0 && d->aux_sb2 % 8 == 0 && (!d->mask || d->mask_sm == 0));
-  const long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
-  const long small_tiles = (long)((d->M + 63) / 64) * ((d->N + 63) / 64) * batch;
-  // split-K (fp32 atomics into a ZEROED C) for reductions much longer than the output is wide -- the weight
-  // gradients dW = dY^T X.  Only plain fp32 outputs qualify and the caller must opt in (C zero-initialised).
-  int splits = 1;
   const bool can_split = d->allow_split_k && d->C && !d->Cb && d->epilogue == BMHRL_EPI_LINEAR && !d->relu && !d->mask &&
                          d->dropout_p == 0.f && !d->accumulate && !d->colsum;
-  static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
-  static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
-  bool big = force_tile ? force_tile >= 2 : big_tiles >= big_min;
-  // (128x128 tiles + K split for small outputs: re-measured slower than 64x64 tiles + K split since the deep-prefetch /
-  //  epilogue changes -- V dW 30 vs 23 us, A-out dW 25 vs 18 us; kept behind BMHRL_GEMM_BIGSPLIT=1 as a tuning aid)
-  static const int big_split = getenv("BMHRL_GEMM_BIGSPLIT") ? atoi(getenv("BMHRL_GEMM_BIGSPLIT")) : 0;
-  if (big_split && can_split && !force_tile && d->M >= 128 && d->N >= 128 && big_tiles <= 96 && d->K >= 1024) {
-    // weight gradients with a small output and a long reduction: 128x128 tiles (about 3x the rate of 64x64 ones),
-    // the chip is filled through the K split
-    const int ktiles = (d->K + BK - 1) / BK;
-    int s2 = (int)((256 + big_tiles - 1) / big_tiles);
-    if (s2 > ktiles / 4) s2 = ktiles / 4;
-    if (s2 >= 2) { big = true; splits = s2; }
-  }
-  if (splits == 1 && can_split && !big && small_tiles < 192) {
-    const int ktiles = (d->K + BK - 1) / BK;
-    splits = (int)((512 + small_tiles - 1) / small_tiles);
-    if (splits > ktiles / 4) splits = ktiles / 4;   // >= 256 of K per split
-    if (splits < 1) splits = 1;
-  }
+  const TilePlan tp = tile_plan(d->M, d->N, d->K, batch, can_split);
+  const bool big = tp.big, mid = tp.mid;
+  const int splits = tp.splits;
   hipError_t e;
-  // 128x128 tiles only when they still give every CU (256) a block; otherwise 64x64 tiles fill the chip better.
-  // (256 x 128 tiles, one workgroup of 4 waves x 128 x 64 per CU with 512 registers per wave -- 48 KiB of operands per k-step for
-  // twice the FLOPs of a square tile -- were built and measured SLOWER on every shape: 4096 x 3072 x 1024 48.5 vs 38.5 us,
-  // 8192^3 1025 vs 1097 TF/s: what two co-resident workgroups hide for each other outweighs the lower traffic per FLOP.)
-  // 128 x 64 tiles when 128 x 128 ones would give a CU at most one workgroup (the 4096 x 1024 projections of the video stream:
-  // 256 tiles): two workgroups per CU cover each other's waits -- 4096 x 1024 x 1024 19.3 -> 17.0 us, its dX 16.1 -> 13.7 us;
-  // with more columns (2048, 3072) the square tile's lower traffic per FLOP wins (26.5 vs 31.5 us).  Alone, that is: inside
-  // the captured step, where the audio branch runs next to these GEMMs, the step measured 6.06 - 6.23 ms with them against
-  // 5.95 ms without, so the option is off by default (BMHRL_GEMM_MIDMAX=256 turns it on, BMHRL_GEMM_TILE=3 forces it).
-  static const int mid_max = getenv("BMHRL_GEMM_MIDMAX") ? atoi(getenv("BMHRL_GEMM_MIDMAX")) : 0;
-  const bool mid = force_tile ? force_tile == 3 : (big && splits == 1 && big_tiles <= mid_max);
   if (mid) e = launch<2, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   else if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
   else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);

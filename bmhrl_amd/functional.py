@@ -182,6 +182,9 @@ SEEDS = DropoutSeeds()
 
 
 # ------------------------------------------------------------------------------------------------ step-scoped scratch
+_ARENA_POISON = os.environ.get("BMHRL_ARENA_POISON", "0") == "1"
+
+
 class ScratchState:
     """What a StepScratch hands out, owned by whoever runs the steps (a CaptionTrainer): the fp32 arena, the bf16 pools and
     their sizes.  A captured step bakes the ADDRESSES of these buffers into its graph, so they must live exactly as long as
@@ -191,6 +194,8 @@ class ScratchState:
     def __init__(self):
         self.arena: Optional[torch.Tensor] = None
         self.need = 0
+        self.raw: Optional[torch.Tensor] = None       # never zeroed: outputs their producer writes whole (f32(zero=False))
+        self.need_raw = 0
         self.pool = {}
 
 
@@ -213,6 +218,8 @@ class StepScratch:
         self.state = self.default_state = ScratchState()
         self.off = 0
         self.spill = 0
+        self.off_raw = 0
+        self.spill_raw = 0
         self.cursor = {}
         self.memo = {}
         self._zeroing = None
@@ -241,6 +248,12 @@ class StepScratch:
                 self._zeroing = zero_stream
             else:
                 self.arena[:self.off_of_last_step()].zero_()
+        st = self.state
+        if st.need_raw and (st.raw is None or st.raw.device != device or st.raw.numel() < st.need_raw):
+            st.raw = torch.empty(st.need_raw, device=device)
+        if st.raw is not None and _ARENA_POISON:
+            st.raw.fill_(float("nan"))            # (test aid: a consumer that accumulates into "overwritten" memory shows up)
+        self.off_raw = self.spill_raw = 0
         self.off = self.spill = 0
         self.cursor = {}
         self.memo = {}
@@ -259,13 +272,25 @@ class StepScratch:
     def end_step(self):
         self.join_zero()
         self.need = max(self.need, self.off + self.spill)
+        self.state.need_raw = max(self.state.need_raw, self.off_raw + self.spill_raw)
         self.armed = False
 
-    def f32(self, *shape, device) -> torch.Tensor:
+    def f32(self, *shape, device, zero: bool = True) -> torch.Tensor:
+        """zero=False: the caller's kernel stores every element (e.g. a weight-gradient GEMM that ops.gemm_overwrites()
+        says runs without a K split) -- the slice comes from a second arena that is never filled"""
         n = 1
         for d in shape:
             n *= d
         n4 = (n + 3) & ~3
+        if not zero:
+            r = self.state.raw
+            if not self.armed or r is None or r.device != device or self.off_raw + n4 > r.numel():
+                if self.armed:
+                    self.spill_raw += n4
+                return torch.empty(*shape, device=device)
+            t = r[self.off_raw:self.off_raw + n].view(*shape)
+            self.off_raw += n4
+            return t
         a = self.arena
         if self._zeroing is not None:
             self.join_zero()
@@ -418,7 +443,8 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
     dev = dyb.device
     dw = db = None
     if need_dw:
-        dw = SCRATCH.f32(N, K, device=dev)   # zeroed: the long row reduction may run split-K with fp32 atomics
+        # zeroed when the long row reduction runs split-K with fp32 atomics; the large projections do not split
+        dw = SCRATCH.f32(N, K, device=dev, zero=not ops.gemm_overwrites(N, K, rows))
         ops.gemm(dyb, xb, N, K, rows, lda=ldy, ldb=ldx, a_off=dy_off, b_off=x_off, a_trans=True, b_trans=True, C_f32=dw, ldc=K,
                  allow_split_k=True)
     if need_db:
@@ -709,7 +735,7 @@ class MemAttnFn(torch.autograd.Function):
         # O_h = Cx_h Wv_h^T + bv_h
         dwv = None
         if need[8]:
-            dwv = SCRATCH.f32(D, dm, device=dev)
+            dwv = SCRATCH.f32(D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, rows, H))
             ops.gemm(dOb, Cx, dk, dm, rows, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(1, H), a_strides=(0, dk),
                      b_strides=(0, dmp), C_f32=dwv, ldc=dm, c_strides=(0, dk * dm), allow_split_k=True)
         dCx = zeros(rows, H * dmp, dtype=_BF16, device=dev)
@@ -772,7 +798,7 @@ class MemAttnFn(torch.autograd.Function):
         # Q'_h = Q_h Wk_h
         dwk = None
         if need[6]:
-            dwk = SCRATCH.f32(D, dm, device=dev)
+            dwk = SCRATCH.f32(D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, rows, H))
             ops.gemm(Qb, dQp, dk, dm, rows, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(1, H), a_strides=(0, dk),
                      b_strides=(0, dmp), C_f32=dwk, ldc=dm, c_strides=(0, dk * dm), allow_split_k=True)
         dbq = SCRATCH.f32(D, device=dev) if need[5] else None
@@ -888,7 +914,7 @@ class PairMemAttnFn(torch.autograd.Function):
                  b_strides=(0, dq * w_o.shape[1]), C_bf16=dOb, ldcb=D, cb_strides=(0, R * D), dropout_p=p_drop, seed=s_attn,
                  seed_dev=SEEDS.dev, drop_strides=(0, R * D, D), colsum=dbv, colsum_sb2=D)
         # O_h = Cx_h Wv_h^T + bv_h
-        dwv = SCRATCH.f32(2 * D, dm, device=dev)
+        dwv = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(dOb, Cx, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
                  b_strides=(R * H * dmp, dmp), C_f32=dwv, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
         dCx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
@@ -918,7 +944,7 @@ class PairMemAttnFn(torch.autograd.Function):
         ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
                  C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
         # Q'_h = Q_h Wk_h
-        dwk = SCRATCH.f32(2 * D, dm, device=dev)
+        dwk = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(Qb, dQp, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
                  b_strides=(R * H * dmp, dmp), C_f32=dwk, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
         dbq = SCRATCH.f32(2 * D, device=dev)
@@ -1017,7 +1043,7 @@ class PairSelfAttnFn(torch.autograd.Function):
         db = SCRATCH.f32(2 * 3 * D, device=dev)           # bias gradients [q | k | v] of each half: column sums of its rows
         ops.colsum_bf16_groups(dQKV, 3 * D, db, R, 3 * D, 2, 3 * D)
         w_qkv = SHADOWS.weight(wq[0], wk[0], wv[0], wq[1], wk[1], wv[1])
-        dw = SCRATCH.f32(2 * 3 * D, dq, device=dev)
+        dw = SCRATCH.f32(2 * 3 * D, dq, device=dev, zero=not ops.gemm_overwrites(3 * D, dq, R, 2))
         ops.gemm(dQKV, xb, 3 * D, dq, R, lda=3 * D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
                  b_strides=(0, R * ldx), C_f32=dw, ldc=dq, c_strides=(0, 3 * D * dq), allow_split_k=True)
         dxn = torch.empty(2 * R, dq, device=dev)

@@ -73,6 +73,22 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
 
 
+_SPLITS = {}
+
+
+def gemm_overwrites(M: int, N: int, K: int, batch: int = 1) -> bool:
+    """True when gemm(..., C_f32=..., allow_split_k=True) of this shape stores every element of C exactly once (no K
+    split, no atomics): the output may then be uninitialised memory.  The launcher's own decision (bmhrl_gemm_splits)."""
+    key = (M, N, K, batch)
+    r = _SPLITS.get(key)
+    if r is None:
+        n = int(_lib.load().bmhrl_gemm_splits(M, N, K, batch))
+        if n < 1:
+            raise RuntimeError(f"bmhrl_gemm_splits{key} failed: {n}")
+        r = _SPLITS[key] = n == 1
+    return r
+
+
 def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, ldo,
                   q_off=0, k_off=0, v_off=0, dropout_p=0.0, seed=0, seed_dev=None):
     _need_cuda(Q, K, V, O)

@@ -67,6 +67,11 @@ typedef struct bmhrl_gemm_desc {
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
+/* K splits bmhrl_gemm uses for a plain fp32 output of (M, N) over a reduction of K with allow_split_k set and `batch` =
+ * batch1 * batch2 (the weight-gradient products): 1 = every element of C is stored exactly once, so C may be uninitialised
+ * memory; > 1 = fp32 atomics into a C the caller must have zeroed.  Same decision function as the launcher's.  < 0: bad
+ * arguments. */
+int bmhrl_gemm_splits(int32_t M, int32_t N, int32_t K, int32_t batch);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention forward (flash style, S x S never materialised).

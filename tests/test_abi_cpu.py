@@ -20,11 +20,14 @@ def test_library_builds_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/bmhrl_hip.h but not exported"
     assert set(_lib.PROTOTYPES) | {"bmhrl_hip_arch", "bmhrl_hip_abi_version", "bmhrl_layernorm_bwd_workspace",
-                                    "bmhrl_attention_shared128_bwd_workspace", "bmhrl_attention_max_keys"} == set(syms)
+                                    "bmhrl_attention_shared128_bwd_workspace", "bmhrl_attention_max_keys", "bmhrl_gemm_splits"} == set(syms)
     assert lib.bmhrl_layernorm_bwd_workspace(4096, 1024) == 256 * 2 * 1024      # 4 rows per wave, 4 waves per block: 256 blocks
     assert lib.bmhrl_hip_arch() == b"gfx950"
     assert lib.bmhrl_hip_abi_version() == 11
     assert lib.bmhrl_attention_max_keys() == 10112        # pure host query: the fused kernels' key limit
+    # pure host query too: the video projections' weight gradients store every element once, the caption-side ones split K
+    assert lib.bmhrl_gemm_splits(1024, 1024, 4096, 1) == 1 and lib.bmhrl_gemm_splits(128, 300, 480, 1) > 1
+    assert lib.bmhrl_gemm_splits(0, 4, 4, 1) < 0
 
 
 def test_ops_refuse_cpu_tensors():

@@ -3,6 +3,8 @@ with a synthetic loader that honours the reference's batch contract (SURVEY.md s
 (BASELINE config 3)."""
 from types import SimpleNamespace
 
+import math
+
 import pytest
 import torch
 
@@ -117,6 +119,33 @@ def test_trainer_graph_replay_matches_eager(setup):
         assert plan_ptrs is not None and sum(p != 0 for p in plan_ptrs) > 100
         # ... and the flat gradient bucket is not written at all
         assert float(t2.opt.grad.abs().max()) == 0.0
+
+
+def test_unzeroed_gradient_arena_is_only_ever_overwritten(setup):
+    """Weight-gradient GEMMs that run without a K split get their output from an arena that is never zeroed
+    (StepScratch.f32(zero=False), decided by the launcher's own bmhrl_gemm_splits).  Poisoned with NaN before every step,
+    a captured trainer must produce the losses and weights of the unpoisoned one -- and that arena must actually be in use."""
+    from bmhrl_amd import functional as F, ops
+    from bmhrl_amd.train import CaptionTrainer
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    b = ds.batches[0]
+    cap = b["caption_data"].caption
+    assert ops.gemm_overwrites(1024, 1024, 480) and not ops.gemm_overwrites(128, 300, 480)
+    out = []
+    try:
+        for poison in (False, True):
+            F._ARENA_POISON = poison
+            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+            t.agent.train()
+            losses = [float(t.step(b["feature_stacks"], cap)) for _ in range(3)]
+            assert t.scratch.need_raw > 100000 and t.scratch.raw is not None
+            out.append((losses, t.opt.flat.clone()))
+    finally:
+        F._ARENA_POISON = False
+    (l0, p0), (l1, p1) = out
+    assert all(math.isfinite(x) for x in l1) and bool(torch.isfinite(p1).all())
+    assert all(abs(a - c) < 2e-3 * abs(a) for a, c in zip(l0, l1)), (l0, l1)
+    assert float((p0 - p1).norm() / p0.norm()) < 3e-3
 
 
 def test_phased_adam_graph_equals_the_plain_graph(setup):
