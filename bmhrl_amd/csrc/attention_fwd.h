@@ -732,7 +732,11 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
       }
       // the loads issued at the top are read as K fragments in the NEXT iteration's O^T phase: everything must have landed
       // (they have had the whole iteration).  Deeper rings (NS = 5, 6: a split's stage is 8 KiB, up to 7 fit the DS immediate)
-      // that keep this iteration's pieces in flight across the barrier were measured SLOWER: loop 16.8-17.0 k vs 15.9 k cycles
+      // that keep this iteration's pieces in flight across the barrier were measured SLOWER: loop 16.8-17.0 k vs 15.9 k cycles.
+      // So was spreading a wave's four pieces over the MFMA gaps (one per four gaps, the barrier moved to the middle of the
+      // iteration so that late pieces have half an iteration more to land: 14.5 vs 13.7 us on the V<-A launch, 34.4 vs 33.4
+      // at Sq = Sk = 800); a loop body per wave slot (different gaps for different waves) sends the register allocator into
+      // scratch (+150 .. 520 bytes of private segment at 256 registers), which costs more per launch than anything it can win
       if constexpr (BMHRL_ABL & 1) return;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
