@@ -364,6 +364,14 @@ def _use_flash(dk: int, Sq: int, Sk: int) -> bool:
     return dk == 256 and Sq >= 128 and Sk <= ops.attention_max_keys()
 
 
+SMALL_ATTN = os.environ.get("BMHRL_SMALL_ATTN", "1") == "1"      # one-launch attention core for Sq, Sk <= 32 (A/B switch)
+
+
+def _use_small(dk, Sq, Sk, *lds_and_offs) -> bool:
+    """the one-launch core of short sequences (csrc/small_attention.hip): caption self attention, goal attention"""
+    return SMALL_ATTN and all(v % 8 == 0 for v in lds_and_offs) and ops.small_attention_ok(Sq, Sk, dk)
+
+
 def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, msq, B, H, Sq, Sk, dk, p_drop, seed):
     """Returns (O bf16 [B*Sq, H*dk] with the reference's output dropout applied, stats) where stats is
     ('flash', row_max, row_sum) or ('mat', P bf16 [B,H,Sq,Skp])."""
@@ -371,6 +379,12 @@ def _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldv, mask, msb, ms
     D = H * dk
     scale = 1.0 / math.sqrt(dk)
     O = torch.empty(B * Sq, D, dtype=_BF16, device=dev)
+    if _use_small(dk, Sq, Sk, ldq, ldk, ldv, q_off, k_off, v_off):
+        Skp = pad8(Sk)
+        P = torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)           # (the kernel writes the padding columns as zero)
+        ops.small_attention_fwd(Qb, Kb, Vb, O, P, Skp, mask, msb, msq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, D, q_off=q_off,
+                                k_off=k_off, v_off=v_off, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+        return O, ("mat", P)
     if _use_flash(dk, Sq, Sk):
         rmax = torch.empty(B, H, Sq, device=dev)
         rsum = torch.empty(B, H, Sq, device=dev)
@@ -403,6 +417,14 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     """dOb: gradient w.r.t. the PRE-dropout attention output (bf16 [B*Sq, D]); Ob: saved post-dropout output.
     Writes bf16 dQ/dK/dV into column slices of the given buffers.  db_* = (zeroed fp32 tensor, offset): the column sums
     of dQ / dK / dV (bias gradients of the three projections) are accumulated there by the producing GEMM's epilogue."""
+    if stats[0] == "mat" and _use_small(dk, Sq, Sk, ldq, ldk, ldv, lddq, lddk, lddv, q_off, k_off, v_off, dq_off, dk_off, dv_off):
+        t = lambda d: (None, 0) if d is None else d
+        (bq, oq), (bk, ok), (bv, ov) = t(db_q), t(db_k), t(db_v)
+        ops.small_attention_bwd(dOb, H * dk, stats[1], pad8(Sk), Qb, Kb, Vb, dQb, dKb, dVb, mask, msb, msq, B, H, Sq, Sk, dk,
+                                1.0 / math.sqrt(dk), ldq, ldk, ldv, lddq, lddk, lddv, q_off=q_off, k_off=k_off, v_off=v_off,
+                                dq_off=dq_off, dk_off=dk_off, dv_off=dv_off, dbq=bq, dbk=bk, dbv=bv, dbq_off=oq, dbk_off=ok,
+                                dbv_off=ov)
+        return
     csq = dict(colsum=db_q[0], colsum_off=db_q[1], colsum_sb2=dk) if db_q is not None else {}
     csk = dict(colsum=db_k[0], colsum_off=db_k[1], colsum_sb2=dk) if db_k is not None else {}
     csv = dict(colsum=db_v[0], colsum_off=db_v[1], colsum_sb2=dk) if db_v is not None else {}

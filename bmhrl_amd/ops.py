@@ -102,6 +102,36 @@ def attention_fwd(Q, K, V, O, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq
                                                dropout_p, seed, _p(seed_dev), stream()), "bmhrl_attention_fwd")
 
 
+def small_attention_ok(Sq: int, Sk: int, dk: int) -> bool:
+    """shapes bmhrl_small_attention_fwd / _bwd serve (pure host query)"""
+    return bool(_lib.load().bmhrl_small_attention_ok(Sq, Sk, dk))
+
+
+def small_attention_fwd(Q, K, V, O, P, ldp, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv, ldo,
+                        q_off=0, k_off=0, v_off=0, dropout_p=0.0, seed=0, seed_dev=None):
+    """one launch: O (bf16 [B*Sq, ldo]) = dropout(softmax(scale Q K^T, masked) V), P (bf16 (B, H, Sq, ldp)) kept for backward"""
+    _need_cuda(Q, K, V, O, P)
+    _lib.check(_lib.load().bmhrl_small_attention_fwd(Q.data_ptr() + 2 * q_off, ldq, K.data_ptr() + 2 * k_off, ldk,
+                                                     V.data_ptr() + 2 * v_off, ldv, O.data_ptr(), ldo, P.data_ptr(), ldp, _p(mask),
+                                                     mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, dropout_p, seed, _p(seed_dev),
+                                                     stream()), "bmhrl_small_attention_fwd")
+
+
+def small_attention_bwd(dO, lddo, P, ldp, Q, K, V, dQ, dK, dV, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale, ldq, ldk, ldv,
+                        lddq, lddk, lddv, q_off=0, k_off=0, v_off=0, dq_off=0, dk_off=0, dv_off=0, dbq=None, dbk=None, dbv=None,
+                        dbq_off=0, dbk_off=0, dbv_off=0):
+    """one launch: dQ / dK / dV (bf16, written into column slices) and optionally the bias gradients dbq / dbk / dbv
+    (fp32 (H * dk) at the given element offsets, added to)"""
+    _need_cuda(dO, P, Q, K, V, dQ, dK, dV)
+    fp = lambda t, off: None if t is None else t.data_ptr() + 4 * off
+    _lib.check(_lib.load().bmhrl_small_attention_bwd(dO.data_ptr(), lddo, P.data_ptr(), ldp, Q.data_ptr() + 2 * q_off, ldq,
+                                                     K.data_ptr() + 2 * k_off, ldk, V.data_ptr() + 2 * v_off, ldv,
+                                                     dQ.data_ptr() + 2 * dq_off, lddq, dK.data_ptr() + 2 * dk_off, lddk,
+                                                     dV.data_ptr() + 2 * dv_off, lddv, fp(dbq, dbq_off), fp(dbk, dbk_off),
+                                                     fp(dbv, dbv_off), _p(mask), mask_sb, mask_sq, B, H, Sq, Sk, dk, scale,
+                                                     stream()), "bmhrl_small_attention_bwd")
+
+
 def attention_shared128_fwd(Qp, X, ctx, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, ldq, ldx, ldo):
     """absorbed-projection attention: Qp (B,Sq,H,128), X (B,Sk,128) shared by all heads -> ctx (B,Sq,H,128)"""
     _need_cuda(Qp, X, ctx)

@@ -132,6 +132,27 @@ int bmhrl_attention_max_keys(void);
  * (41: 4 x 1, 22: 2 x 2), 0 = automatic (the default).  Process-wide, not thread-safe; results do not depend on it. */
 int bmhrl_attention_config(int32_t head_dim, int32_t code);
 
+/* Attention core of SHORT sequences (Sq, Sk <= 32; d_k in {64, 128, 256, 512}) as one launch per direction: the caption
+ * self attention of the fusion layers and the worker's goal attention (model/multihead_attention.py:7-31 on the 30 caption
+ * positions).  Q / K / V / O / dO / dQ / dK / dV are bf16 row-major matrices whose row b * S + i holds the heads side by side
+ * (head h at columns [h * d_k, (h + 1) * d_k) of the given pointer), P is bf16 (B, H, Sq, ldp) with ldp = Sk rounded up to 8
+ * (padding columns written as zero) -- the probabilities the backward needs.  mask: bytes, mask[b * mask_sb + q * mask_sq +
+ * key] == 0 -> the score is the reference's -1e9 fill (mask_sq = 0: one key mask per batch row); dropout on the OUTPUT with
+ * element id (b * Sq + q) * H * d_k + h * d_k + d, like the context GEMM's epilogue it replaces.  Backward: dO is the gradient
+ * of the pre-dropout output; the row term of the softmax is sum_k P dP from the same rounded P; masked keys get no score
+ * gradient; dbq / dbk / dbv (optional, fp32 (H * d_k)) receive the column sums of dQ / dK / dV by atomic adds.
+ * bmhrl_small_attention_ok: 1 when the shape is served. */
+int bmhrl_small_attention_ok(int32_t Sq, int32_t Sk, int32_t dk);
+int bmhrl_small_attention_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
+                              int64_t ldo, void* P, int32_t ldp, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                              int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t dk, float scale, float dropout_p,
+                              uint64_t seed, const uint64_t* seed_dev, bmhrl_stream_t stream);
+int bmhrl_small_attention_bwd(const void* dO, int64_t lddo, const void* P, int32_t ldp, const void* Q, int64_t ldq,
+                              const void* K, int64_t ldk, const void* V, int64_t ldv, void* dQ, int64_t lddq, void* dK,
+                              int64_t lddk, void* dV, int64_t lddv, float* dbq, float* dbk, float* dbv, const uint8_t* mask,
+                              int64_t mask_sb, int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk, int32_t dk,
+                              float scale, bmhrl_stream_t stream);
+
 /* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
  * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */
 int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
