@@ -41,8 +41,13 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ dO, long lddo, cons
 }
 
 // Row softmax for the materialised small-Sq path: one wave per row, fp32 in, bf16 out.
+// (rpg > 0: the bf16 rows come in groups of rpg consecutive rows, group g at g * pgs elements -- P and dS of the paired
+// memory attentions share a buffer, interleaved per query: functional.PairMemAttnFn)
+__device__ __forceinline__ long grouped_row(long row, long ld, int rpg, long pgs) {
+  return rpg > 0 ? (row / rpg) * pgs + (row % rpg) * ld : row * ld;
+}
 __global__ void softmax_rows_kernel(const float* __restrict__ S, long lds, bf16_t* __restrict__ P, long ldp, long rows,
-                                    int cols) {
+                                    int cols, int rpg, long pgs) {
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -54,7 +59,7 @@ __global__ void softmax_rows_kernel(const float* __restrict__ S, long lds, bf16_
   for (int c = lane; c < cols; c += 64) l += __expf(s[c] - m);
   l = wave_sum(l);
   const float inv = 1.f / l;
-  bf16_t* pr = P + row * ldp;
+  bf16_t* pr = P + grouped_row(row, ldp, rpg, pgs);
   for (int c = lane; c < cols; c += 64) pr[c] = (bf16_t)(__expf(s[c] - m) * inv);
 }
 
@@ -65,16 +70,16 @@ __global__ void softmax_rows_kernel(const float* __restrict__ S, long lds, bf16_
 __global__ void softmax_bwd_rows_kernel(const bf16_t* __restrict__ P, long ldp, const float* __restrict__ dP, long lddp,
                                         bf16_t* __restrict__ dS, long ldds, long rows, int cols, float scale,
                                         const uint8_t* __restrict__ mask, long mask_sb, long mask_sq, int rows_per_query,
-                                        int queries) {
+                                        int queries, int rpg, long pgs) {
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const bf16_t* p = P + row * ldp;
+  const bf16_t* p = P + grouped_row(row, ldp, rpg, pgs);
   const float* g = dP + row * lddp;
   float acc = 0.f;
   for (int c = lane; c < cols; c += 64) acc = fmaf((float)p[c], g[c], acc);
   const float delta = wave_sum(acc);
-  bf16_t* o = dS + row * ldds;
+  bf16_t* o = dS + grouped_row(row, ldds, rpg, pgs);
   // masked_fill: the score of a masked key is a constant, no gradient reaches it (only a fully masked row has P != 0 there)
   const long q = row / rows_per_query;
   const uint8_t* m = mask ? mask + (q / queries) * mask_sb + (q % queries) * mask_sq : nullptr;
@@ -121,21 +126,24 @@ extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int
 
 extern "C" int bmhrl_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lddp, void* dS, int64_t ldds,
                                       int64_t rows, int32_t cols, float scale, const uint8_t* mask, int64_t mask_sb,
-                                      int64_t mask_sq, int32_t rows_per_query, int32_t queries, bmhrl_stream_t stream) {
+                                      int64_t mask_sq, int32_t rows_per_query, int32_t queries, int32_t rows_per_group,
+                                      int64_t group_stride, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(P && dP && dS && rows > 0 && cols > 0 && ldp >= cols && lddp >= cols && ldds >= cols);
+  BMHRL_CHECK_ARG(rows_per_group >= 0 && (rows_per_group == 0 || (ldp == ldds && group_stride >= (int64_t)rows_per_group * ldp)));
   BMHRL_CHECK_ARG(!mask || (rows_per_query > 0 && queries > 0 && rows % ((int64_t)rows_per_query * queries) == 0));
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipLaunchKernelGGL(softmax_bwd_rows_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)P, (long)ldp, dP, (long)lddp,
                      (bf16_t*)dS, (long)ldds, (long)rows, cols, scale, mask, (long)mask_sb, (long)mask_sq,
-                     mask ? rows_per_query : 1, mask ? queries : 1);
+                     mask ? rows_per_query : 1, mask ? queries : 1, rows_per_group, (long)group_stride);
   return hip_status(hipGetLastError());
 }
 
 extern "C" int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
-                                  bmhrl_stream_t stream) {
+                                  int32_t rows_per_group, int64_t group_stride, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(S && P && rows > 0 && cols > 0);
+  BMHRL_CHECK_ARG(rows_per_group >= 0 && (rows_per_group == 0 || group_stride >= (int64_t)rows_per_group * ldp));
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, (hipStream_t)stream, S, (long)lds, (bf16_t*)P, (long)ldp,
-                     (long)rows, cols);
+                     (long)rows, cols, rows_per_group, (long)group_stride);
   return hip_status(hipGetLastError());
 }

@@ -830,6 +830,10 @@ TilePlan tile_plan(int M, int N, int K, int batch, bool can_split) {
   static const int force_tile = getenv("BMHRL_GEMM_TILE") ? atoi(getenv("BMHRL_GEMM_TILE")) : 0;  // 1 = 64x64, 2 = 128x128 (tuning aid)
   static const long big_min = getenv("BMHRL_GEMM_BIGMIN") ? atol(getenv("BMHRL_GEMM_BIGMIN")) : 256;
   bool big = force_tile ? force_tile >= 2 : big_tiles >= big_min;
+  // an output with at most `small_dim` rows or columns (the 30 caption positions against a memory: scores, contexts and
+  // their gradients, batched over samples x heads) wastes 3/4 of a 128-wide tile where a 64-wide one wastes half
+  static const int small_dim = getenv("BMHRL_GEMM_SMALLDIM") ? atoi(getenv("BMHRL_GEMM_SMALLDIM")) : 64;
+  if (!force_tile && (M <= small_dim || N <= small_dim)) big = false;
   // (128x128 tiles + K split for small outputs: re-measured slower than 64x64 tiles + K split since the deep-prefetch /
   //  epilogue changes -- V dW 30 vs 23 us, A-out dW 25 vs 18 us; kept behind BMHRL_GEMM_BIGSPLIT=1 as a tuning aid)
   static const int big_split = getenv("BMHRL_GEMM_BIGSPLIT") ? atoi(getenv("BMHRL_GEMM_BIGSPLIT")) : 0;

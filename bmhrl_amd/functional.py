@@ -880,19 +880,25 @@ class PairMemAttnFn(torch.autograd.Function):
                  C_bf16=Qb, ldcb=D, cb_strides=(0, R * D), bias=SHADOWS.bias(*bq), bias_sb2=D)
         memb = xb if self_att else SCRATCH.memo_bf16(mem, B * Sk, dm, copies=2)
         zeros = torch.zeros if dmp != dm else torch.empty
-        Qp = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        # Q' and (in the backward) dCx share one buffer, P and dS another, interleaved per query: row (sample, query) holds
+        # [slot 0: H heads | slot 1: H heads].  Slot 0 = P / dCx, slot 1 = dS / Q' -- so that d(mem) = sum_h P_h^T dCx_h +
+        # dS_h^T Q'_h of a sample is ONE product over the 2 L H rows of the sample (one pass over the fp32 d(mem) instead of a
+        # write, a read-modify-write and a sum of the two stacks)
+        QD = zeros(2 * R, 2 * H * dmp, dtype=_BF16, device=dev)
+        ldqd, ldpd = 2 * H * dmp, 2 * H * Skp
         ldk = w_k.shape[1]
         ops.gemm(Qb, w_k, R, dm, dk, lda=D, ldb=ldk, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
-                 b_strides=(D * ldk, dk * ldk), C_bf16=Qp, ldcb=H * dmp, cb_strides=(R * H * dmp, dmp))
+                 b_strides=(D * ldk, dk * ldk), C_bf16=QD, ldcb=ldqd, cb_off=H * dmp, cb_strides=(R * ldqd, dmp))
         m8, msb, msq = _mask_u8(mask)            # the caller passes the mask of 2 B samples
         assert m8 is None or m8.shape[0] == B2
         Cx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
         S = torch.empty(B2, L, H, Skp, device=dev)
-        ops.gemm(Qp, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B2, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
-                 C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb, mask_sm=msq)
-        P = _padded_bf16(B2 * L * H, Sk, dev).view(B2, L, H, Skp)
-        ops.softmax_rows(S, Skp, P, Skp, B2 * L * H, Sk)
-        ops.gemm(P, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=(L * H * Skp, Skp),
+        ops.gemm(QD, memb, L, Sk, dm, lda=ldqd, ldb=dmp, a_off=H * dmp, batch=(B2, H), a_strides=(L * ldqd, dmp),
+                 b_strides=(Sk * dmp, 0), C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb,
+                 mask_sm=msq)
+        PD = _padded_bf16(B2 * L * 2 * H, Sk, dev)                  # (B2, L, 2, H, Skp)
+        ops.softmax_rows(S, Skp, PD, Skp, B2 * L * H, Sk, rows_per_group=H, group_stride=ldpd)
+        ops.gemm(PD, memb, L, dm, Sk, lda=ldpd, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=(L * ldpd, Skp),
                  b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
         Ob = torch.empty(2 * R, D, dtype=_BF16, device=dev)
         ldv = w_v.shape[1]
@@ -903,14 +909,14 @@ class PairMemAttnFn(torch.autograd.Function):
         ops.gemm(Ob, w_o, R, dq, D, lda=D, ldb=w_o.shape[1], batch=(1, 2), a_strides=(0, R * D), b_strides=(0, dq * w_o.shape[1]),
                  C_f32=y, ldc=dq, c_strides=(0, R * dq), bias=SHADOWS.bias(*bo), bias_sb2=dq, residual=x2, ldr=dq,
                  r_strides=(0, R * dq), dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, drop_strides=(0, R * dq, dq))
-        ctx.save_for_backward(x2, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, m8, P, *params)
+        ctx.save_for_backward(x2, mean, rstd, xb, memb, Qb, QD, Cx, Ob, m8, PD, *params)
         ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq)
         return y
 
     @staticmethod
     def backward(ctx, dy2):
         B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq = ctx.cfg
-        x2, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, m8, P = ctx.saved_tensors[:11]
+        x2, mean, rstd, xb, memb, Qb, QD, Cx, Ob, m8, PD = ctx.saved_tensors[:11]
         params = ctx.saved_tensors[11:]
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = zip(params[:10], params[10:])
         dev = dy2.device
@@ -939,32 +945,30 @@ class PairMemAttnFn(torch.autograd.Function):
         dwv = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(dOb, Cx, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
                  b_strides=(R * H * dmp, dmp), C_f32=dwv, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
-        dCx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        ldqd, ldpd = 2 * H * dmp, 2 * H * Skp       # (see forward: slot 0 = P / dCx, slot 1 = dS / Q')
         ops.gemm(dOb, w_v, R, dm, dk, lda=D, ldb=ldv, b_trans=True, batch=(2, H), a_strides=(R * D, dk), b_strides=(D * ldv, dk * ldv),
-                 C_bf16=dCx, ldcb=H * dmp, cb_strides=(R * H * dmp, dmp))
+                 C_bf16=QD, ldcb=ldqd, cb_strides=(R * ldqd, dmp))
         # dS = scale * P (dP - sum_k P dP), the row term from P and dP themselves (see MemAttnFn.backward)
-        dS = _padded_bf16(B2 * L * H, Sk, dev).view(B2, L, H, Skp)
-        pstr = (L * H * Skp, Skp)
         dP = torch.empty(B2, L, H, Skp, device=dev)
-        ops.gemm(dCx, memb, L, Sk, dm, lda=H * dmp, ldb=dmp, batch=(B2, H), a_strides=(L * H * dmp, dmp), b_strides=(Sk * dmp, 0),
-                 C_f32=dP, ldc=H * Skp, c_strides=pstr)
-        ops.softmax_bwd_rows(P, Skp, dP, Skp, dS, Skp, B2 * L * H, Sk, scale, m8, msb, msq, H, L)
+        ops.gemm(QD, memb, L, Sk, dm, lda=ldqd, ldb=dmp, batch=(B2, H), a_strides=(L * ldqd, dmp), b_strides=(Sk * dmp, 0),
+                 C_f32=dP, ldc=H * Skp, c_strides=(L * H * Skp, Skp))
+        ops.softmax_bwd_rows(PD, Skp, dP, Skp, PD, Skp, B2 * L * H, Sk, scale, m8, msb, msq, H, L, rows_per_group=H,
+                             group_stride=ldpd, ds_off=H * Skp)
 
-        def grad_mem(target, first_accumulates):      # d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h, b over the 2 B samples
-            ops.gemm(P, dCx, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B2, 1),
-                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
-                     accumulate=first_accumulates)
-            ops.gemm(dS, Qp, Sk, dm, L * H, lda=Skp, ldb=dmp, a_trans=True, b_trans=True, batch=(B2, 1),
-                     a_strides=(L * H * Skp, 0), b_strides=(L * H * dmp, 0), C_f32=target, ldc=dm, c_strides=(Sk * dm, 0),
-                     accumulate=True)
+        def grad_mem(target, c_off, c_sb, accumulate):
+            """d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h: one product over the sample's 2 L H rows, stack by stack (the
+            second stack's launch adds to what the first wrote when both read the same memory)"""
+            for half in range(2):
+                ops.gemm(PD, QD, Sk, dm, 2 * L * H, lda=Skp, ldb=dmp, a_off=half * B * L * ldpd, b_off=half * B * L * ldqd,
+                         a_trans=True, b_trans=True, batch=(B, 1), a_strides=(L * ldpd, 0), b_strides=(L * ldqd, 0), C_f32=target,
+                         ldc=dm, c_off=c_off[half], c_strides=(c_sb, 0), accumulate=accumulate[half])
         dmem = None
         if need[1] and not self_att:
-            dmem2 = torch.empty(B2, Sk, dm, device=dev)
-            grad_mem(dmem2, False)
-            dmem = dmem2[:B] + dmem2[B:]                # both halves read the same memory
+            dmem = torch.empty(B, Sk, dm, device=dev)   # both halves read the same memory
+            grad_mem(dmem, (0, 0), Sk * dm, (False, True))
         dQp = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
-        ops.gemm(dS, memb, L, dm, Sk, lda=H * Skp, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=pstr, b_strides=(Sk * dmp, 0),
-                 C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        ops.gemm(PD, memb, L, dm, Sk, lda=ldpd, ldb=dmp, a_off=H * Skp, b_trans=True, batch=(B2, H), a_strides=(L * ldpd, Skp),
+                 b_strides=(Sk * dmp, 0), C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
         # Q'_h = Q_h Wk_h
         dwk = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(Qb, dQp, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
@@ -981,10 +985,9 @@ class PairMemAttnFn(torch.autograd.Function):
         dxn = torch.empty(2 * R, dq, device=dev)
         ops.gemm(dQb, w_q, R, dq, D, lda=D, ldb=w_q.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * D),
                  b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq))
-        if self_att:
-            grad_mem(dxn, True)                         # the keys / values are LN(x) too
+        if self_att:                                    # the keys / values are LN(x) too: each half its own
+            grad_mem(dxn, (0, R * dq), Sk * dm, (True, True))
         dx2 = torch.empty(2, B, L, dq, device=dev)
-        dln = []
         dlnw2, dlnb2 = SCRATCH.f32(2 * dq, device=dev), SCRATCH.f32(2 * dq, device=dev)
         ops.layernorm_bwd_groups(dxn, x2, SHADOWS.bias(*ln_w), mean, rstd, dx2, dy2, dlnw2, dlnb2, R, dq, 2)
         dln = [(dlnw2[i * dq:(i + 1) * dq], dlnb2[i * dq:(i + 1) * dq]) for i in range(2)]

@@ -159,16 +159,19 @@ def attention_shared128_bwd(Qp, X, dCx, row_max, row_sum, delta, mask, mask_sb, 
                "bmhrl_attention_shared128_bwd")
 
 
-def softmax_bwd_rows(P, ldp, dP, lddp, dS, ldds, rows, cols, scale, mask=None, mask_sb=0, mask_sq=0, rows_per_query=1, queries=1):
-    """dS = scale * P * (dP - rowsum(P * dP)), 0 at masked keys; P bf16, dP fp32, dS bf16; rows = (sample, query, rows_per_query)"""
+def softmax_bwd_rows(P, ldp, dP, lddp, dS, ldds, rows, cols, scale, mask=None, mask_sb=0, mask_sq=0, rows_per_query=1, queries=1,
+                     rows_per_group=0, group_stride=0, p_off=0, ds_off=0):
+    """dS = scale * P * (dP - rowsum(P * dP)), 0 at masked keys; P bf16, dP fp32, dS bf16; rows = (sample, query, rows_per_query).
+    rows_per_group > 0: P and dS rows in groups of that many, group g at g * group_stride elements (+ p_off / ds_off)"""
     _need_cuda(P, dP, dS)
-    _lib.check(_lib.load().bmhrl_softmax_bwd_rows(P.data_ptr(), ldp, dP.data_ptr(), lddp, dS.data_ptr(), ldds, rows, cols, scale,
-                                                  _p(mask), mask_sb, mask_sq, rows_per_query, queries, stream()),
-               "bmhrl_softmax_bwd_rows")
+    _lib.check(_lib.load().bmhrl_softmax_bwd_rows(P.data_ptr() + 2 * p_off, ldp, dP.data_ptr(), lddp, dS.data_ptr() + 2 * ds_off, ldds,
+                                                  rows, cols, scale, _p(mask), mask_sb, mask_sq, rows_per_query, queries,
+                                                  rows_per_group, group_stride, stream()), "bmhrl_softmax_bwd_rows")
 
 
-def softmax_rows(S, lds, P, ldp, rows, cols):
-    _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr(), ldp, rows, cols, stream()), "bmhrl_softmax_rows")
+def softmax_rows(S, lds, P, ldp, rows, cols, rows_per_group=0, group_stride=0, p_off=0):
+    _lib.check(_lib.load().bmhrl_softmax_rows(S.data_ptr(), lds, P.data_ptr() + 2 * p_off, ldp, rows, cols, rows_per_group,
+                                              group_stride, stream()), "bmhrl_softmax_rows")
 
 
 def attn_delta(dO, lddo, O, ldo, delta, B, H, Sq, dk, scale=1.0):

@@ -155,8 +155,10 @@ int bmhrl_small_attention_bwd(const void* dO, int64_t lddo, const void* P, int32
 
 /* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
  * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */
-int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols,
-                       bmhrl_stream_t stream);
+/* rows_per_group > 0: the bf16 rows (P here; P and dS in the backward) are laid out in groups of rows_per_group consecutive
+ * rows, group g starting g * group_stride elements into the buffer (0: plain rows with the leading dimension) */
+int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols, int32_t rows_per_group,
+                       int64_t group_stride, bmhrl_stream_t stream);
 
 /* Backward of the same row softmax (autograd of F.softmax + masked_fill in attention(), model/multihead_attention.py:22-25):
  * dS[r][c] = scale * P[r][c] * (dP[r][c] - sum_k P[r][k] dP[r][k]), 0 where the key is masked; P bf16 (rows, ldp), dP fp32
@@ -164,7 +166,8 @@ int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_
  * is addressed mask[sample * mask_sb + query * mask_sq + c] (0 = masked). */
 int bmhrl_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lddp, void* dS, int64_t ldds,
                            int64_t rows, int32_t cols, float scale, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
-                           int32_t rows_per_query, int32_t queries, bmhrl_stream_t stream);
+                           int32_t rows_per_query, int32_t queries, int32_t rows_per_group, int64_t group_stride,
+                           bmhrl_stream_t stream);
 
 /* delta[b,h,q] = scale * sum_d dO[b,q,h,d] * O[b,q,h,d]   (softmax backward row term) */
 int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale,
