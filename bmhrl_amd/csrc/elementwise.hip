@@ -681,7 +681,8 @@ __global__ void fusion_tail_fwd_kernel(const float* __restrict__ ca, const float
 // backward of the same: dca / dcv, and (atomic +=, zeroed by the caller) d gamma / d beta of both norms and d a_v of the row's
 // group.  A block walks RPB rows of ONE group (blockIdx.y); its four waves keep per-column partial sums in registers and add
 // them up through LDS: one atomic per column and block.
-constexpr int TAIL_RPB = 16, TAIL_MAXD = 512;   // (4 rows per wave: 60 blocks per group at 480 rows; 64 rows per block ran 15 us on 16 CUs)
+constexpr int TAIL_RPB = 8, TAIL_MAXD = 512;    // (2 rows per wave, both in flight: 120 blocks per group at 480 rows; 4 rows one after
+                                                //  the other ran 22-27 us inside the step, 64 rows per block 15 us on 16 CUs)
 template <int NC>
 __global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ ca,
                                                               const float* __restrict__ cv, const float* __restrict__ stats,
@@ -706,18 +707,40 @@ __global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __res
   }
   float da = 0.f;
   const long r_end = min((long)(blockIdx.x + 1) * TAIL_RPB, rows_per_group);
-  for (long r = (long)blockIdx.x * TAIL_RPB + wave; r < r_end; r += 4) {
+  static_assert(TAIL_RPB == 8, "a wave owns rows w and w + 4 of the block: both rows' loads are requested before either is reduced");
+  struct RowIn { float ma, ra, mv, rv, xa[NC], xv[NC], d[NC]; };
+  auto load_row = [&](const long r, RowIn& R) {
+    const long row = grp * rows_per_group + (r < r_end ? r : r_end - 1);
+    R.ma = stats[row]; R.ra = stats[rows + row]; R.mv = stats[2 * rows + row]; R.rv = stats[3 * rows + row];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      const bool in = c < D;
+      R.xa[i] = in ? ca[row * D + c] : 0.f;
+      R.xv[i] = in ? cv[row * D + c] : 0.f;
+      R.d[i] = in ? dout[row * D + c] : 0.f;
+    }
+  };
+  RowIn R2[2];
+  const long rw = (long)blockIdx.x * TAIL_RPB + wave;
+  load_row(rw, R2[0]);
+  load_row(rw + 4, R2[1]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long r = rw + 4 * k;
+    if (r >= r_end) break;
+    const RowIn& R = R2[k];
     const long row = grp * rows_per_group + r;
-    const float ma = stats[row], ra = stats[rows + row], mv = stats[2 * rows + row], rv = stats[3 * rows + row];
+    const float ma = R.ma, ra = R.ra, mv = R.mv, rv = R.rv;
     float ha[NC], hv[NC], d[NC];
     float s1a = 0.f, s2a = 0.f, s1v = 0.f, s2v = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       const bool in = c < D;
-      ha[i] = in ? (ca[row * D + c] - ma) * ra : 0.f;
-      hv[i] = in ? (cv[row * D + c] - mv) * rv : 0.f;
-      d[i] = in ? dout[row * D + c] : 0.f;
+      ha[i] = in ? (R.xa[i] - ma) * ra : 0.f;
+      hv[i] = in ? (R.xv[i] - mv) * rv : 0.f;
+      d[i] = R.d[i];
       const float dya = (1.f - gate) * d[i], dyv = gate * d[i];
       da += d[i] * ((hv[i] * gv[i] + bv[i]) - (ha[i] * ga[i] + ba[i]));
       dga[i] += dya * ha[i]; dba[i] += dya;

@@ -459,7 +459,7 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
 # ------------------------------------------------------------------------------------------------ linear helpers
 def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx, dx_f32=None, dx_bf16=None, lddxb=0,
                 dx_epilogue=ops.EPI_LINEAR, dx_alpha=1.0, dx_aux=None, ldaux=0, dx_drop=0.0, dx_seed=0,
-                dy_off=0, x_off=0, w_off=0, dx_accumulate=False, dx_colsum=None):
+                dy_off=0, x_off=0, w_off=0, dx_accumulate=False, dx_colsum=None, dx_split_k=False):
     """Gradients of y = x W^T + b given dy (bf16 [rows, N] at dy_off, leading dim ldy).
     dW (fp32 [N, K]) = dy^T x ; db = column sums of dy ; dx = dy W (fp32 and/or bf16, optional fused epilogue)."""
     dev = dyb.device
@@ -475,7 +475,8 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
     if need_dx:
         ops.gemm(dyb, wb, rows, K, N, lda=ldy, ldb=wb.shape[1], a_off=dy_off, b_off=w_off, b_trans=True, C_f32=dx_f32,
                  ldc=K, C_bf16=dx_bf16, ldcb=lddxb, epilogue=dx_epilogue, alpha=dx_alpha, aux=dx_aux, ldaux=ldaux,
-                 dropout_p=dx_drop, seed=dx_seed, seed_dev=SEEDS.dev, accumulate=dx_accumulate, colsum=dx_colsum)
+                 dropout_p=dx_drop, seed=dx_seed, seed_dev=SEEDS.dev, accumulate=dx_accumulate, colsum=dx_colsum,
+                 allow_split_k=dx_split_k)            # (dx_split_k: dx_f32 is ZEROED -- few output tiles, long reduction)
     return dw, db
 
 
@@ -982,9 +983,9 @@ class PairMemAttnFn(torch.autograd.Function):
         dwq = SCRATCH.f32(2 * D, dq, device=dev)
         ops.gemm(dQb, xb, D, dq, R, lda=D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * D),
                  b_strides=(0, R * ldx), C_f32=dwq, ldc=dq, c_strides=(0, D * dq), allow_split_k=True)
-        dxn = torch.empty(2 * R, dq, device=dev)
+        dxn = SCRATCH.f32(2 * R, dq, device=dev)         # (zeroed: split K, as in PairSelfAttnFn)
         ops.gemm(dQb, w_q, R, dq, D, lda=D, ldb=w_q.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * D),
-                 b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq))
+                 b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True)
         if self_att:                                    # the keys / values are LN(x) too: each half its own
             grad_mem(dxn, (0, R * dq), Sk * dm, (True, True))
         dx2 = torch.empty(2, B, L, dq, device=dev)
@@ -1071,9 +1072,9 @@ class PairSelfAttnFn(torch.autograd.Function):
         dw = SCRATCH.f32(2 * 3 * D, dq, device=dev, zero=not ops.gemm_overwrites(3 * D, dq, R, 2))
         ops.gemm(dQKV, xb, 3 * D, dq, R, lda=3 * D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
                  b_strides=(0, R * ldx), C_f32=dw, ldc=dq, c_strides=(0, 3 * D * dq), allow_split_k=True)
-        dxn = torch.empty(2 * R, dq, device=dev)
+        dxn = SCRATCH.f32(2 * R, dq, device=dev)         # (zeroed: 80 output tiles over a reduction of 3 D -> split K)
         ops.gemm(dQKV, w_qkv, R, dq, 3 * D, lda=3 * D, ldb=w_qkv.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
-                 b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq))
+                 b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True)
         dx2 = torch.empty(2, B, L, dq, device=dev)
         out = []
         dlnw2, dlnb2 = SCRATCH.f32(2 * dq, device=dev), SCRATCH.f32(2 * dq, device=dev)
@@ -1500,9 +1501,10 @@ class WorkerHeadFn(torch.autograd.Function):
             gb = SCRATCH.bf16(rows, V, dev)
             ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
         wb = SHADOWS.weight_split3(w)                           # block 0 of both operands = the plain bf16 copies
-        dcat = torch.empty(rows, K, device=dev) if (need[0] or need[1]) else None
+        # d cat[x, gc] = d logits W: 480 x 364 outputs over a reduction of V = 10 172 -- 48 tiles; split over K it fills the chip
+        dcat = SCRATCH.f32(rows, K, device=dev) if (need[0] or need[1]) else None
         dw, db = _linear_bwd(gb, gb.shape[1], rows, V, xb, xb.shape[1], K, wb, need_dw=need[2], need_db=need[3],
-                             need_dx=dcat is not None, dx_f32=dcat)
+                             need_dx=dcat is not None, dx_f32=dcat, dx_split_k=True)
         dx = dgc = None
         if dcat is not None:
             dcat = dcat.view(B, L, K)
