@@ -50,6 +50,7 @@ class GemmDesc(C.Structure):
 # name -> argtypes (every entry point of include/bmhrl_hip.h; tests check the .so exports all of them)
 PROTOTYPES = {
     "bmhrl_gemm": [C.POINTER(GemmDesc), ptr],
+    "bmhrl_gemm_group": [C.POINTER(GemmDesc), i32, ptr],
     "bmhrl_attention_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, i32, i32, i32, i32, i32, f32,
                             f32, u64, ptr, ptr],
     "bmhrl_attention_shared128_fwd": [ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i32, i32, i32, i32, f32, ptr],

@@ -32,7 +32,7 @@ struct GemmArgs {
   const bf16_t* aux; long ldaux, aux_sb1, aux_sb2;
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
   float* colsum; long cs_sb2, bias_sb2, cs_sb1, bias_sb1;
-  int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16, fast_pd;
+  int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16, fast_pd, tiles_mn;
 };
 
 constexpr int BK = 64;
@@ -41,7 +41,7 @@ constexpr int BK = 64;
 // 4*(lane>>5)) go through LDS (`smem`: SMEM_ELEMS bf16 elements, free once every wave is past the main loop).
 template <int TM, int TN, int SMEM_ELEMS>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], bf16_t* smem, const int b1, const int b2,
-                                              const int m0, const int n0) {
+                                              const int m0, const int n0, const int split) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   const bf16_t* __restrict__ AUXg = p.aux ? p.aux + b1 * p.aux_sb1 + b2 * p.aux_sb2 : nullptr;
   const uint64_t seed = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
   const uint64_t drop_base = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
-  const bool first_split = blockIdx.y == 0;
+  const bool first_split = split == 0;
   const float* __restrict__ biasp = (first_split && p.bias) ? p.bias + b1 * p.bias_sb1 + b2 * p.bias_sb2 : nullptr;
   if (!first_split) Rg = nullptr;
 
@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 }
 
 template <int TM, int TN, bool AT, bool BT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const int by, const int bz) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // LDS row strides (elements).  k-contiguous tiles: +8 (16 B) keeps ds_read_b128 conflict free;
   // transposed tiles ([k][m]): +32 (64 B) puts the 4 rows of a tr-read block on disjoint bank quarters.
@@ -359,15 +359,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
   const int r32 = lane & 31, h = lane >> 5;
   const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 
-  const int bz = blockIdx.z, b1 = bz / p.batch2, b2 = bz % p.batch2;
-  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int b1 = bz / p.batch2, b2 = bz % p.batch2;
+  const int tile_m = bx % p.tiles_m, tile_n = bx / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bf16_t* __restrict__ Ag = p.A + b1 * p.a_sb1 + b2 * p.a_sb2;
   const bf16_t* __restrict__ Bg = p.B + b1 * p.b_sb1 + b2 * p.b_sb2;
   const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
   // split-K: this block reduces k in [k_begin, k_end)
-  const int k_begin = blockIdx.y * p.k_per_split;
+  const int k_begin = by * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int K8 = (k_end == p.K) ? ((p.K + 7) & ~7) : k_end;
 
@@ -523,7 +523,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
   }
 
-  gemm_epilogue<TM, TN, 2 * (A_ELEMS + B_ELEMS)>(p, acc, smem, b1, b2, m0, n0);    // (every step ends in a barrier)
+  gemm_epilogue<TM, TN, 2 * (A_ELEMS + B_ELEMS)>(p, acc, smem, b1, b2, m0, n0, by);    // (every step ends in a barrier)
+}
+
+template <int TM, int TN, bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+  gemm_body<TM, TN, AT, BT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Up to four independent problems of the same kernel variant in ONE launch (the leaf weight-gradient products of a fusion
+// layer's backward: each is a few microseconds of work behind a launch, and nothing but the optimizer waits for them).
+// Block b belongs to the problem whose range [first[i], first[i + 1]) holds it; inside its problem the blocks are ordered
+// (batch, split, tile).  The problem's arguments are picked field by field with uniform selects (an indexed copy of a
+// kernel-argument struct would live in scratch memory).
+struct GemmGroup {
+  GemmArgs p0, p1, p2, p3;
+  int first[5];
+  int n;
+};
+template <int TM, int TN, bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(const GemmGroup g) {
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  if (g.n > 1 && b >= g.first[1]) i = 1;
+  if (g.n > 2 && b >= g.first[2]) i = 2;
+  if (g.n > 3 && b >= g.first[3]) i = 3;
+  GemmArgs p = g.p0;
+  if (i == 1) p = g.p1;
+  if (i == 2) p = g.p2;
+  if (i == 3) p = g.p3;
+  int r = b - g.first[i];
+  const int bx = r % p.tiles_mn;
+  r /= p.tiles_mn;
+  gemm_body<TM, TN, AT, BT>(p, bx, r % p.splits, r / p.splits);
 }
 
 
@@ -768,7 +800,14 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();             // every wave is done with the stages: the epilogue reuses them
   asm volatile("" ::: "memory");
-  gemm_epilogue<TM, TN, SMEM_ELEMS>(p, acc, smem, b1, b2, m0, n0);
+  gemm_epilogue<TM, TN, SMEM_ELEMS>(p, acc, smem, b1, b2, m0, n0, (int)blockIdx.y);
+}
+
+// direct-to-LDS main loop: whole k-tiles only (no zero fill of a ragged reduction tail) and 32-bit lane offsets
+bool uses_glds(const GemmArgs& a, int a_trans, int b_trans) {
+  static const int no_glds = getenv("BMHRL_GEMM_NOGLDS") ? atoi(getenv("BMHRL_GEMM_NOGLDS")) : 0;       // (tuning aid: A/B)
+  const long a_span = (a_trans ? 64 : (long)a.M) * a.lda * 2, b_span = (b_trans ? 64 : (long)a.N) * a.ldb * 2;
+  return !no_glds && a.K % BK == 0 && a_span < (1l << 31) && b_span < (1l << 31) && a.M >= 8 && a.N >= 8;
 }
 
 template <int TM, int TN>
@@ -777,15 +816,13 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
   constexpr int BM = 64 * TM, BN = 64 * TN;
   p.tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
+  p.tiles_mn = p.tiles_m * tiles_n;
   p.splits = splits;
   p.dbg = getenv("BMHRL_GEMM_DBG") ? atoi(getenv("BMHRL_GEMM_DBG")) : 0;
   const int ktiles = (a.K + BK - 1) / BK;
   p.k_per_split = ((ktiles + splits - 1) / splits) * BK;
   dim3 grid(p.tiles_m * tiles_n, splits, batch), block(256);
-  // direct-to-LDS main loop: whole k-tiles only (no zero fill of a ragged reduction tail) and 32-bit lane offsets
-  static const int no_glds = getenv("BMHRL_GEMM_NOGLDS") ? atoi(getenv("BMHRL_GEMM_NOGLDS")) : 0;       // (tuning aid: A/B)
-  const long a_span = (a_trans ? 64 : (long)a.M) * a.lda * 2, b_span = (b_trans ? 64 : (long)a.N) * a.ldb * 2;
-  const bool glds = !no_glds && a.K % BK == 0 && a_span < (1l << 31) && b_span < (1l << 31) && a.M >= 8 && a.N >= 8;
+  const bool glds = uses_glds(a, a_trans, b_trans);
   if (glds) {
     // stages: 2 for the 128 x 128 tiles (two workgroups per CU cover each other's waits; four stages at one workgroup per
     // CU measured equal or slower on every shape of the step: these sizes are bound by the ~70 GB/s a CU gets from L2 into
@@ -876,7 +913,9 @@ extern "C" int bmhrl_gemm_splits(int32_t M, int32_t N, int32_t K, int32_t batch)
   return tile_plan(M, N, K, batch, true).splits;
 }
 
-extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
+namespace {
+// argument checks + the kernel's argument block + tile / split decision of one problem
+int prepare(const bmhrl_gemm_desc* d, GemmArgs& a, TilePlan& tp, int& batch) {
   BMHRL_CHECK_ARG(d && d->A && d->B && (d->C || d->Cb));
   BMHRL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->batch1 > 0 && d->batch2 > 0);
   BMHRL_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0);
@@ -889,7 +928,6 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   if (d->epilogue == BMHRL_EPI_DSCORE || d->epilogue == BMHRL_EPI_RELU_BWD) BMHRL_CHECK_ARG(d->aux != nullptr);
   if (d->epilogue == BMHRL_EPI_PROB) BMHRL_CHECK_ARG(d->rowvec2 != nullptr);
   BMHRL_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f);
-  GemmArgs a;
   a.M = d->M; a.N = d->N; a.K = d->K; a.batch2 = d->batch2;
   a.A = (const bf16_t*)d->A; a.lda = d->lda; a.a_sb1 = d->a_sb1; a.a_sb2 = d->a_sb2;
   a.B = (const bf16_t*)d->B; a.ldb = d->ldb; a.b_sb1 = d->b_sb1; a.b_sb2 = d->b_sb2;
@@ -907,7 +945,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   if (a.drop_sb1 == 0 && a.drop_sb2 == 0 && a.drop_sm == 0) {
     a.drop_sm = d->N; a.drop_sb2 = (long)d->M * d->N; a.drop_sb1 = a.drop_sb2 * d->batch2;
   }
-  const int batch = d->batch1 * d->batch2;
+  batch = d->batch1 * d->batch2;
   // vector (8/16-byte) epilogue accesses need aligned bases and leading dimensions
   auto al = [](const void* q, uintptr_t a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
   a.vec_ok = al(d->C, 16) && d->ldc % 4 == 0 && d->c_sb1 % 4 == 0 && d->c_sb2 % 4 == 0 && al(d->Cb, 8) && d->ldcb % 4 == 0 &&
@@ -923,12 +961,66 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
                d->aux_sb1 % 8 == 0 && d->aux_sb2 % 8 == 0 && (!d->mask || d->mask_sm == 0));
   const bool can_split = d->allow_split_k && d->C && !d->Cb && d->epilogue == BMHRL_EPI_LINEAR && !d->relu && !d->mask &&
                          d->dropout_p == 0.f && !d->accumulate && !d->colsum;
-  const TilePlan tp = tile_plan(d->M, d->N, d->K, batch, can_split);
-  const bool big = tp.big, mid = tp.mid;
-  const int splits = tp.splits;
+  tp = tile_plan(d->M, d->N, d->K, batch, can_split);
+  return 0;
+}
+}  // namespace
+
+extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
+  GemmArgs a;
+  TilePlan tp;
+  int batch;
+  if (const int rc = prepare(d, a, tp, batch)) return rc;
   hipError_t e;
-  if (mid) e = launch<2, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
-  else if (big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
-  else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, splits, (hipStream_t)stream);
+  if (tp.mid) e = launch<2, 1>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
+  else if (tp.big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
+  else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
   return hip_status(e);
+}
+
+// n <= 4 independent problems as ONE launch when all of them are 64 x 64-tile problems of the same operand layout on the
+// register-staged main loop (reductions that are not a multiple of 64: the caption-side weight gradients, K = B L); any other
+// mix is launched one by one -- same results either way.
+extern "C" int bmhrl_gemm_group(const bmhrl_gemm_desc* d, int32_t n, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(d && n >= 1);
+  if (n > 4) {
+    for (int i = 0; i < n; i += 4)
+      if (const int rc = bmhrl_gemm_group(d + i, n - i < 4 ? n - i : 4, stream)) return rc;
+    return 0;
+  }
+  GemmGroup g;
+  GemmArgs* ps[4] = {&g.p0, &g.p1, &g.p2, &g.p3};
+  bool same = n > 1;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    TilePlan tp;
+    int batch;
+    if (const int rc = prepare(d + i, *ps[i], tp, batch)) return rc;
+    GemmArgs& p = *ps[i];
+    same = same && !tp.big && !tp.mid && d[i].a_trans == d[0].a_trans && d[i].b_trans == d[0].b_trans &&
+           !uses_glds(p, d[i].a_trans, d[i].b_trans);
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_mn = p.tiles_m * ((p.N + 63) / 64);
+    p.splits = tp.splits;
+    p.dbg = 0;
+    const int ktiles = (p.K + BK - 1) / BK;
+    p.k_per_split = ((ktiles + tp.splits - 1) / tp.splits) * BK;
+    g.first[i] = total;
+    total += p.tiles_mn * tp.splits * batch;
+  }
+  if (!same) {
+    for (int i = 0; i < n; ++i)
+      if (const int rc = bmhrl_gemm(d + i, stream)) return rc;
+    return 0;
+  }
+  for (int i = n; i < 5; ++i) g.first[i] = total;
+  for (int i = n; i < 4; ++i) *ps[i] = g.p0;
+  g.n = n;
+  dim3 grid((unsigned)total), block(256);
+  const hipStream_t s = (hipStream_t)stream;
+  if (!d[0].a_trans && !d[0].b_trans) hipLaunchKernelGGL((gemm_group_kernel<1, 1, false, false>), grid, block, 0, s, g);
+  else if (!d[0].a_trans && d[0].b_trans) hipLaunchKernelGGL((gemm_group_kernel<1, 1, false, true>), grid, block, 0, s, g);
+  else if (d[0].a_trans && !d[0].b_trans) hipLaunchKernelGGL((gemm_group_kernel<1, 1, true, false>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_group_kernel<1, 1, true, true>), grid, block, 0, s, g);
+  return hip_status(hipGetLastError());
 }

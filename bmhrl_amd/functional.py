@@ -934,9 +934,10 @@ class PairMemAttnFn(torch.autograd.Function):
         dbo = SCRATCH.f32(2 * dq, device=dev)
         ops.cast_colsum_bf16(dy2, dq, dyb, ldx, 2 * R, dq, dbo, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, group_rows=R,
                              colsum_stride=dq)
+        leaf = []                                       # weight-gradient products: one grouped launch at the end (ops.gemm_flush)
         dwo = SCRATCH.f32(2 * dq, D, device=dev)
         ops.gemm(dyb, Ob, dq, D, R, lda=ldx, ldb=D, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
-                 b_strides=(0, R * D), C_f32=dwo, ldc=D, c_strides=(0, dq * D), allow_split_k=True)
+                 b_strides=(0, R * D), C_f32=dwo, ldc=D, c_strides=(0, dq * D), allow_split_k=True, defer=leaf)
         dOb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
         dbv = SCRATCH.f32(2 * D, device=dev)
         ops.gemm(dyb, w_o, R, D, dq, lda=ldx, ldb=w_o.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
@@ -945,7 +946,7 @@ class PairMemAttnFn(torch.autograd.Function):
         # O_h = Cx_h Wv_h^T + bv_h
         dwv = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(dOb, Cx, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
-                 b_strides=(R * H * dmp, dmp), C_f32=dwv, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
+                 b_strides=(R * H * dmp, dmp), C_f32=dwv, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True, defer=leaf)
         ldqd, ldpd = 2 * H * dmp, 2 * H * Skp       # (see forward: slot 0 = P / dCx, slot 1 = dS / Q')
         ops.gemm(dOb, w_v, R, dm, dk, lda=D, ldb=ldv, b_trans=True, batch=(2, H), a_strides=(R * D, dk), b_strides=(D * ldv, dk * ldv),
                  C_bf16=QD, ldcb=ldqd, cb_strides=(R * ldqd, dmp))
@@ -973,7 +974,7 @@ class PairMemAttnFn(torch.autograd.Function):
         # Q'_h = Q_h Wk_h
         dwk = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(Qb, dQp, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),
-                 b_strides=(R * H * dmp, dmp), C_f32=dwk, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True)
+                 b_strides=(R * H * dmp, dmp), C_f32=dwk, ldc=dm, c_strides=(D * dm, dk * dm), allow_split_k=True, defer=leaf)
         dbq = SCRATCH.f32(2 * D, device=dev)
         dQb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
         ops.gemm(dQp, w_k, R, dk, dm, lda=H * dmp, ldb=ldk, batch=(2, H), a_strides=(R * H * dmp, dmp), b_strides=(D * ldk, dk * ldk),
@@ -982,7 +983,8 @@ class PairMemAttnFn(torch.autograd.Function):
         # Q projection and LayerNorm
         dwq = SCRATCH.f32(2 * D, dq, device=dev)
         ops.gemm(dQb, xb, D, dq, R, lda=D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * D),
-                 b_strides=(0, R * ldx), C_f32=dwq, ldc=dq, c_strides=(0, D * dq), allow_split_k=True)
+                 b_strides=(0, R * ldx), C_f32=dwq, ldc=dq, c_strides=(0, D * dq), allow_split_k=True, defer=leaf)
+        ops.gemm_flush(leaf)
         dxn = SCRATCH.f32(2 * R, dq, device=dev)         # (zeroed: split K, as in PairSelfAttnFn)
         ops.gemm(dQb, w_q, R, dq, D, lda=D, ldb=w_q.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * D),
                  b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True)
@@ -1056,9 +1058,10 @@ class PairSelfAttnFn(torch.autograd.Function):
         ops.cast_colsum_bf16(dy2, dq, dyb, ldx, 2 * R, dq, dbo, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, group_rows=R,
                              colsum_stride=dq)
         w_o = SHADOWS.weight(*wo)
+        leaf = []                                       # the two weight-gradient products: one grouped launch
         dwo = SCRATCH.f32(2 * dq, D, device=dev)
         ops.gemm(dyb, Ob, dq, D, R, lda=ldx, ldb=D, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
-                 b_strides=(0, R * D), C_f32=dwo, ldc=D, c_strides=(0, dq * D), allow_split_k=True)
+                 b_strides=(0, R * D), C_f32=dwo, ldc=D, c_strides=(0, dq * D), allow_split_k=True, defer=leaf)
         dOb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
         ops.gemm(dyb, w_o, R, D, dq, lda=ldx, ldb=w_o.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * ldx),
                  b_strides=(0, dq * w_o.shape[1]), C_bf16=dOb, ldcb=D, cb_strides=(0, R * D), dropout_p=p_drop, seed=s_attn,
@@ -1071,7 +1074,8 @@ class PairSelfAttnFn(torch.autograd.Function):
         w_qkv = SHADOWS.weight(wq[0], wk[0], wv[0], wq[1], wk[1], wv[1])
         dw = SCRATCH.f32(2 * 3 * D, dq, device=dev, zero=not ops.gemm_overwrites(3 * D, dq, R, 2))
         ops.gemm(dQKV, xb, 3 * D, dq, R, lda=3 * D, ldb=ldx, a_trans=True, b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
-                 b_strides=(0, R * ldx), C_f32=dw, ldc=dq, c_strides=(0, 3 * D * dq), allow_split_k=True)
+                 b_strides=(0, R * ldx), C_f32=dw, ldc=dq, c_strides=(0, 3 * D * dq), allow_split_k=True, defer=leaf)
+        ops.gemm_flush(leaf)
         dxn = SCRATCH.f32(2 * R, dq, device=dev)         # (zeroed: 80 output tiles over a reduction of 3 D -> split K)
         ops.gemm(dQKV, w_qkv, R, dq, 3 * D, lda=3 * D, ldb=w_qkv.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
                  b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True)

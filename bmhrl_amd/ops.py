@@ -3,6 +3,7 @@ every call is enqueued on torch's current HIP stream.  No wrapper has a CPU path
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -49,8 +50,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          epilogue=EPI_LINEAR, alpha=1.0, relu=False, accumulate=False, bias=None, residual=None, ldr=0,
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
          aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False,
-         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0, bias_sb2=0, colsum_sb1=0, bias_sb1=0) -> None:
-    """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers."""
+         colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0, bias_sb2=0, colsum_sb1=0, bias_sb1=0,
+         defer: Optional[list] = None) -> None:
+    """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers.
+    defer: a list -- the problem is appended to it instead of launched; gemm_flush(list) then launches up to four of them as
+    ONE kernel (bmhrl_gemm_group: leaf products nothing in between depends on)."""
     _need_cuda(A, B, C_f32, C_bf16)
     d = _lib.GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -70,7 +74,23 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.drop_sb1, d.drop_sb2, d.drop_sm = drop_strides
     d.colsum = None if colsum is None else colsum.data_ptr() + 4 * colsum_off; d.colsum_sb2 = colsum_sb2
     d.bias_sb2 = bias_sb2; d.bias_sb1 = bias_sb1; d.colsum_sb1 = colsum_sb1
+    if defer is not None and _GROUP_LEAVES:
+        defer.append((d, (A, B, C_f32, C_bf16, bias, residual, mask, rowvec, rowvec2, aux, seed_dev, colsum)))   # (operands kept alive)
+        return
     _lib.check(_lib.load().bmhrl_gemm(C.byref(d), stream()), "bmhrl_gemm")
+
+
+_GROUP_LEAVES = os.environ.get("BMHRL_GEMM_GROUP", "1") == "1"      # (A/B switch: 0 launches deferred problems at once)
+
+
+def gemm_flush(deferred: list) -> None:
+    """launch the problems collected with gemm(..., defer=deferred): one kernel per up to four of them when they share a
+    kernel variant, one by one otherwise (bmhrl_gemm_group decides)"""
+    if not deferred:
+        return
+    arr = (_lib.GemmDesc * len(deferred))(*[d for d, _ in deferred])
+    _lib.check(_lib.load().bmhrl_gemm_group(arr, len(deferred), stream()), "bmhrl_gemm_group")
+    deferred.clear()
 
 
 _SPLITS = {}

@@ -67,6 +67,10 @@ typedef struct bmhrl_gemm_desc {
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
+/* n independent problems; up to four at a time run as ONE launch when they are 64 x 64-tile problems of the same operand
+ * layout on the register-staged main loop (reductions that are no multiple of 64), any other mix one by one.  Same results
+ * as n calls of bmhrl_gemm.  Meant for leaf products (the caption-side weight gradients of a fusion layer's backward). */
+int bmhrl_gemm_group(const bmhrl_gemm_desc* descs, int32_t n, bmhrl_stream_t stream);
 /* K splits bmhrl_gemm uses for a plain fp32 output of (M, N) over a reduction of K with allow_split_k set and `batch` =
  * batch1 * batch2 (the weight-gradient products): 1 = every element of C is stored exactly once, so C may be uninitialised
  * memory; > 1 = fp32 atomics into a C the caller must have zeroed.  Same decision function as the launcher's.  < 0: bad

@@ -622,6 +622,46 @@ def test_layernorm_groups_equal_one_launch_per_group(dev, rows, D):
     assert rel_err(dg, dg1) < 1e-5 and rel_err(db, db1) < 1e-5
 
 
+def test_gemm_group_equals_separate_launches(dev):
+    """bmhrl_gemm_group: up to four weight-gradient style products (dY^T X, fp32 outputs, K no multiple of 64, different shapes,
+    batches and K splits) as one launch == the same problems launched one by one; a mix that cannot share a kernel (a
+    128-tile problem among them) takes the one-by-one path with the same results"""
+    from bmhrl_amd import ops
+    torch.manual_seed(21)
+    R = 480
+    shapes = [(300, 1024, 2), (256, 128, 8), (1024, 300, 2), (64, 72, 1), (3072, 300, 2)]
+    def problems(big_one):
+        out = []
+        for (N, K, nb) in shapes[:5]:
+            dy = (torch.randn(nb * R, ((N + 7) // 8) * 8, device=dev) * 0.3).bfloat16()
+            x = (torch.randn(nb * R, ((K + 7) // 8) * 8, device=dev) * 0.3).bfloat16()
+            out.append((dy, x, N, K, nb))
+        if big_one:
+            dy = (torch.randn(4096, 1024, device=dev) * 0.1).bfloat16()
+            x = (torch.randn(4096, 1024, device=dev) * 0.1).bfloat16()
+            out.append((dy, x, 1024, 1024, 1))
+        return out
+    for big_one in (False, True):
+        probs = problems(big_one)
+        got, ref, leaf = [], [], []
+        for dy, x, N, K, nb in probs:
+            rows = dy.shape[0] // nb
+            kw = dict(lda=dy.shape[1], ldb=x.shape[1], a_trans=True, b_trans=True, batch=(1, nb), a_strides=(0, rows * dy.shape[1]),
+                      b_strides=(0, rows * x.shape[1]), ldc=K, c_strides=(0, N * K), allow_split_k=True)
+            c1, c2 = torch.zeros(nb * N, K, device=dev), torch.zeros(nb * N, K, device=dev)
+            ops.gemm(dy, x, N, K, rows, C_f32=c1, defer=leaf, **kw)
+            ops.gemm(dy, x, N, K, rows, C_f32=c2, **kw)
+            got.append(c1); ref.append(c2)
+        assert all(float(c.abs().max()) == 0.0 for c in got)          # nothing ran yet
+        ops.gemm_flush(leaf)
+        assert leaf == []
+        for (dy, x, N, K, nb), a, b in zip(probs, got, ref):
+            rows = dy.shape[0] // nb
+            exact = torch.einsum("brn,brk->bnk", dy.float().view(nb, rows, -1)[..., :N],
+                                 x.float().view(nb, rows, -1)[..., :K]).reshape(nb * N, K)
+            assert rel_err(a, b) < 1e-5 and rel_err(a, exact) < 1e-3, (N, K, nb)
+
+
 def test_grouped_colsum_and_copied_cast(dev):
     """bmhrl_colsum_bf16_groups == bmhrl_colsum_bf16 per group; bmhrl_cast_bf16_copies == bmhrl_cast_bf16 per copy"""
     from bmhrl_amd import ops
