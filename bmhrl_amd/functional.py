@@ -459,16 +459,18 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
 # ------------------------------------------------------------------------------------------------ linear helpers
 def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx, dx_f32=None, dx_bf16=None, lddxb=0,
                 dx_epilogue=ops.EPI_LINEAR, dx_alpha=1.0, dx_aux=None, ldaux=0, dx_drop=0.0, dx_seed=0,
-                dy_off=0, x_off=0, w_off=0, dx_accumulate=False, dx_colsum=None, dx_split_k=False):
+                dy_off=0, x_off=0, w_off=0, dx_accumulate=False, dx_colsum=None, dx_split_k=False, leaf=None):
     """Gradients of y = x W^T + b given dy (bf16 [rows, N] at dy_off, leading dim ldy).
-    dW (fp32 [N, K]) = dy^T x ; db = column sums of dy ; dx = dy W (fp32 and/or bf16, optional fused epilogue)."""
+    dW (fp32 [N, K]) = dy^T x ; db = column sums of dy ; dx = dy W (fp32 and/or bf16, optional fused epilogue).
+    leaf: a list -- the dW product is deferred into it (the caller launches the block's weight gradients together with
+    ops.gemm_flush; see bmhrl_gemm_group)."""
     dev = dyb.device
     dw = db = None
     if need_dw:
         # zeroed when the long row reduction runs split-K with fp32 atomics; the large projections do not split
         dw = SCRATCH.f32(N, K, device=dev, zero=not ops.gemm_overwrites(N, K, rows))
         ops.gemm(dyb, xb, N, K, rows, lda=ldy, ldb=ldx, a_off=dy_off, b_off=x_off, a_trans=True, b_trans=True, C_f32=dw, ldc=K,
-                 allow_split_k=True)
+                 allow_split_k=True, defer=leaf)
     if need_db:
         db = SCRATCH.f32(N, device=dev)
         ops.colsum_bf16(dyb, ldy, db, True, rows, N, dy_off=dy_off)
@@ -584,8 +586,11 @@ class MHAFn(torch.autograd.Function):
         # linear_d2Q backward; its dx is d(attention output), taken back through the output dropout in the epilogue
         dOb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
         w_o = SHADOWS.weight(wo)
+        # the weight gradients of a short block (caption side: 480 rows) leave as one grouped launch at the end; long ones
+        # (the encoder's: 4096 / 12 800 rows, a kernel each anyway) stay next to the dY they read
+        leaf = [] if max(rows_q, rows_k) < 2048 else None
         dwo, _ = _linear_bwd(dyb, ldx, rows_q, dq, Ob, D, D, w_o, need_dw=need[10], need_db=False, need_dx=True,
-                             dx_bf16=dOb, lddxb=D, dx_drop=p_drop, dx_seed=s_attn)
+                             dx_bf16=dOb, lddxb=D, dx_drop=p_drop, dx_seed=s_attn, leaf=leaf)
         del keep
         if self_att:
             dQKV = torch.empty(rows_q, 3 * D, dtype=_BF16, device=dev)
@@ -618,7 +623,7 @@ class MHAFn(torch.autograd.Function):
             w_qkv = SHADOWS.weight(wq, wk, wv)
             need_w = need[4] or need[6] or need[8]
             dw, _ = _linear_bwd(dQKV, 3 * D, rows_q, 3 * D, xb, ldx, dq, w_qkv, need_dw=need_w, need_db=False,
-                                need_dx=dxn is not None, dx_f32=dxn)
+                                need_dx=dxn is not None, dx_f32=dxn, leaf=leaf)
             db = db_all
             if dw is not None:
                 dwq, dwk, dwv = dw[:D], dw[D:2 * D], dw[2 * D:]
@@ -628,17 +633,19 @@ class MHAFn(torch.autograd.Function):
             w_q = SHADOWS.weight(wq)
             w_kv = SHADOWS.weight(wk, wv)
             dwq, _ = _linear_bwd(dQb, D, rows_q, D, xb, ldx, dq, w_q, need_dw=need[4], need_db=False,
-                                 need_dx=dxn is not None, dx_f32=dxn)
+                                 need_dx=dxn is not None, dx_f32=dxn, leaf=leaf)
             dbq = db_qq
             if need[1]:
                 dkv_in = torch.empty(B, Sk, dkv, device=dev)
             dw, _ = _linear_bwd(dKV, 2 * D, rows_k, 2 * D, kvb, kvb.shape[1], dkv, w_kv, need_dw=need[6] or need[8],
-                                need_db=False, need_dx=need[1], dx_f32=dkv_in)
+                                need_db=False, need_dx=need[1], dx_f32=dkv_in, leaf=leaf)
             db = db_kv
             if dw is not None:
                 dwk, dwv = dw[:D], dw[D:]
             if db is not None:
                 dbk, dbv = db[:D], db[D:]
+        if leaf:
+            ops.gemm_flush(leaf)
         dx = dlnw = dlnb = None
         if has_ln:
             if dxn is not None:
