@@ -64,6 +64,9 @@ PROTOTYPES = {
                                   u64, ptr, ptr],
     "bmhrl_small_attention_bwd": [ptr, i64, ptr, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr,
                                   ptr, i64, i64, i32, i32, i32, i32, i32, f32, ptr],
+    "bmhrl_cast_memory": [ptr, ptr, ptr, i32, i32, i32, i32, ptr],
+    "bmhrl_memory_attention": [i32, ptr, i64, ptr, i64, ptr, i64, i32, ptr, i64, i64, ptr, i64, ptr, i64, i32, i32, i32, i32, i32,
+                               i32, f32, ptr],
     "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, i32, i64, ptr],
     "bmhrl_softmax_bwd_rows": [ptr, i64, ptr, i64, ptr, i64, i64, i32, f32, ptr, i64, i64, i32, i32, i32, i64, ptr],
     "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
@@ -138,6 +141,8 @@ def load() -> C.CDLL:
     lib.bmhrl_attention_shared128_bwd_workspace.argtypes = [i32, i32, i32]
     lib.bmhrl_attention_shared128_bwd_workspace.restype = C.c_int64
     lib.bmhrl_attention_max_keys.restype = C.c_int
+    lib.bmhrl_memory_attention_ok.argtypes = [i32, i32, i32]
+    lib.bmhrl_memory_attention_ok.restype = C.c_int
     lib.bmhrl_small_attention_ok.argtypes = [i32, i32, i32]
     lib.bmhrl_small_attention_ok.restype = C.c_int
     lib.bmhrl_gemm_splits.argtypes = [i32, i32, i32, i32]

@@ -317,6 +317,23 @@ class StepScratch:
             self.memo[key] = (weakref.ref(t), buf)
         return buf
 
+    def memo_mem(self, t: torch.Tensor, B: int, Sk: int, dm: int):
+        """(bf16 copy (B * Sk, dm), per-sample transposed bf16 copy (B, dm, ldt), ldt) of the fp32 memory t (B, Sk, dm) for
+        ops.memory_attention -- one launch, made once per distinct tensor inside a step (both fusion layers of both stacks
+        read the same encoder output)"""
+        key = (t.data_ptr(), t._version, B, Sk, dm, "T")
+        if self.armed:
+            hit = self.memo.get(key)
+            if hit is not None and hit[0]() is t:
+                return hit[1]
+        ldt = (Sk + 15) & ~15
+        y = torch.empty(B * Sk, dm, dtype=_BF16, device=t.device)
+        yt = torch.empty(B, dm, ldt, dtype=_BF16, device=t.device)
+        ops.cast_memory(t.contiguous(), y, yt, B, Sk, dm, ldt)
+        if self.armed:
+            self.memo[key] = (weakref.ref(t), (y, yt, ldt))
+        return y, yt, ldt
+
     def zeroed_bf16(self, rows: int, cols: int, device) -> torch.Tensor:
         """(rows, cols) bf16 buffer that was zero when created and whose users only ever write the same body columns
         (pooled inside a step like bf16(); a fresh zero tensor outside)"""
@@ -364,6 +381,9 @@ def _use_flash(dk: int, Sq: int, Sk: int) -> bool:
     return dk == 256 and Sq >= 128 and Sk <= ops.attention_max_keys()
 
 
+# one-launch few-query memory attention core (csrc/memory_attention.hip): measured slower than the three launches it replaces on
+# the video side (44 vs 35 us), so off by default
+FUSED_MEMATTN = os.environ.get("BMHRL_FUSED_MEMATTN", "0") == "1"
 SMALL_ATTN = os.environ.get("BMHRL_SMALL_ATTN", "1") == "1"      # one-launch attention core for Sq, Sk <= 32 (A/B switch)
 
 
@@ -886,7 +906,14 @@ class PairMemAttnFn(torch.autograd.Function):
         Qb = torch.empty(2 * R, D, dtype=_BF16, device=dev)
         ops.gemm(xb, w_q, R, D, dq, lda=ldx, ldb=w_q.shape[1], batch=(1, 2), a_strides=(0, R * ldx), b_strides=(0, D * w_q.shape[1]),
                  C_bf16=Qb, ldcb=D, cb_strides=(0, R * D), bias=SHADOWS.bias(*bq), bias_sb2=D)
-        memb = xb if self_att else SCRATCH.memo_bf16(mem, B * Sk, dm, copies=2)
+        # score -> softmax -> context (and dP -> dS -> dQ' in the backward) as ONE launch per direction where the shape allows
+        # (csrc/memory_attention.hip: 30 queries against 256 x 1024 / 800 x 128 memories)
+        fused = FUSED_MEMATTN and not self_att and dmp == dm and ops.memory_attention_ok(L, Sk, dm)
+        memT, ldt = None, 0
+        if fused:
+            memb, memT, ldt = SCRATCH.memo_mem(mem, B, Sk, dm)
+        else:
+            memb = xb if self_att else SCRATCH.memo_bf16(mem, B * Sk, dm, copies=2)
         zeros = torch.zeros if dmp != dm else torch.empty
         # Q' and (in the backward) dCx share one buffer, P and dS another, interleaved per query: row (sample, query) holds
         # [slot 0: H heads | slot 1: H heads].  Slot 0 = P / dCx, slot 1 = dS / Q' -- so that d(mem) = sum_h P_h^T dCx_h +
@@ -900,14 +927,19 @@ class PairMemAttnFn(torch.autograd.Function):
         m8, msb, msq = _mask_u8(mask)            # the caller passes the mask of 2 B samples
         assert m8 is None or m8.shape[0] == B2
         Cx = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
-        S = torch.empty(B2, L, H, Skp, device=dev)
-        ops.gemm(QD, memb, L, Sk, dm, lda=ldqd, ldb=dmp, a_off=H * dmp, batch=(B2, H), a_strides=(L * ldqd, dmp),
-                 b_strides=(Sk * dmp, 0), C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb,
-                 mask_sm=msq)
         PD = _padded_bf16(B2 * L * 2 * H, Sk, dev)                  # (B2, L, 2, H, Skp)
-        ops.softmax_rows(S, Skp, PD, Skp, B2 * L * H, Sk, rows_per_group=H, group_stride=ldpd)
-        ops.gemm(PD, memb, L, dm, Sk, lda=ldpd, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=(L * ldpd, Skp),
-                 b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        fused = fused and (m8 is None or msq == 0)
+        if fused:
+            ops.memory_attention(False, QD, H * dmp, ldqd, memb, memT, ldt, PD, ldpd, H * Skp, Cx, H * dmp, m8, msb, B, B2, H, L, Sk,
+                                 dm, scale)
+        else:
+            S = torch.empty(B2, L, H, Skp, device=dev)
+            ops.gemm(QD, memb, L, Sk, dm, lda=ldqd, ldb=dmp, a_off=H * dmp, batch=(B2, H), a_strides=(L * ldqd, dmp),
+                     b_strides=(Sk * dmp, 0), C_f32=S, ldc=H * Skp, c_strides=(L * H * Skp, Skp), alpha=scale, mask=m8, mask_sb1=msb,
+                     mask_sm=msq)
+            ops.softmax_rows(S, Skp, PD, Skp, B2 * L * H, Sk, rows_per_group=H, group_stride=ldpd)
+            ops.gemm(PD, memb, L, dm, Sk, lda=ldpd, ldb=dmp, b_trans=True, batch=(B2, H), a_strides=(L * ldpd, Skp),
+                     b_strides=(Sk * dmp, 0), C_bf16=Cx, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
         Ob = torch.empty(2 * R, D, dtype=_BF16, device=dev)
         ldv = w_v.shape[1]
         ops.gemm(Cx, w_v, R, dk, dm, lda=H * dmp, ldb=ldv, batch=(2, H), a_strides=(R * H * dmp, dmp), b_strides=(D * ldv, dk * ldv),
@@ -917,15 +949,15 @@ class PairMemAttnFn(torch.autograd.Function):
         ops.gemm(Ob, w_o, R, dq, D, lda=D, ldb=w_o.shape[1], batch=(1, 2), a_strides=(0, R * D), b_strides=(0, dq * w_o.shape[1]),
                  C_f32=y, ldc=dq, c_strides=(0, R * dq), bias=SHADOWS.bias(*bo), bias_sb2=dq, residual=x2, ldr=dq,
                  r_strides=(0, R * dq), dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, drop_strides=(0, R * dq, dq))
-        ctx.save_for_backward(x2, mean, rstd, xb, memb, Qb, QD, Cx, Ob, m8, PD, *params)
-        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq)
+        ctx.save_for_backward(x2, mean, rstd, xb, memb, Qb, QD, Cx, Ob, m8, PD, memT, *params)
+        ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq, fused, ldt)
         return y
 
     @staticmethod
     def backward(ctx, dy2):
-        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq = ctx.cfg
-        x2, mean, rstd, xb, memb, Qb, QD, Cx, Ob, m8, PD = ctx.saved_tensors[:11]
-        params = ctx.saved_tensors[11:]
+        B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, msb, msq, fused, ldt = ctx.cfg
+        x2, mean, rstd, xb, memb, Qb, QD, Cx, Ob, m8, PD, memT = ctx.saved_tensors[:12]
+        params = ctx.saved_tensors[12:]
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = zip(params[:10], params[10:])
         dev = dy2.device
         R, B2 = B * L, 2 * B
@@ -958,11 +990,16 @@ class PairMemAttnFn(torch.autograd.Function):
         ops.gemm(dOb, w_v, R, dm, dk, lda=D, ldb=ldv, b_trans=True, batch=(2, H), a_strides=(R * D, dk), b_strides=(D * ldv, dk * ldv),
                  C_bf16=QD, ldcb=ldqd, cb_strides=(R * ldqd, dmp))
         # dS = scale * P (dP - sum_k P dP), the row term from P and dP themselves (see MemAttnFn.backward)
-        dP = torch.empty(B2, L, H, Skp, device=dev)
-        ops.gemm(QD, memb, L, Sk, dm, lda=ldqd, ldb=dmp, batch=(B2, H), a_strides=(L * ldqd, dmp), b_strides=(Sk * dmp, 0),
-                 C_f32=dP, ldc=H * Skp, c_strides=(L * H * Skp, Skp))
-        ops.softmax_bwd_rows(PD, Skp, dP, Skp, PD, Skp, B2 * L * H, Sk, scale, m8, msb, msq, H, L, rows_per_group=H,
-                             group_stride=ldpd, ds_off=H * Skp)
+        dQp = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
+        if fused:       # dP -> dS -> dQ' in one launch (dS also lands in its slot of PD for d(mem) below)
+            ops.memory_attention(True, QD, 0, ldqd, memb, memT, ldt, PD, ldpd, H * Skp, dQp, H * dmp, m8, msb, B, B2, H, L, Sk, dm,
+                                 scale)
+        else:
+            dP = torch.empty(B2, L, H, Skp, device=dev)
+            ops.gemm(QD, memb, L, Sk, dm, lda=ldqd, ldb=dmp, batch=(B2, H), a_strides=(L * ldqd, dmp), b_strides=(Sk * dmp, 0),
+                     C_f32=dP, ldc=H * Skp, c_strides=(L * H * Skp, Skp))
+            ops.softmax_bwd_rows(PD, Skp, dP, Skp, PD, Skp, B2 * L * H, Sk, scale, m8, msb, msq, H, L, rows_per_group=H,
+                                 group_stride=ldpd, ds_off=H * Skp)
 
         def grad_mem(target, c_off, c_sb, accumulate):
             """d(mem)[b] = sum_h P_h^T dCx_h + dS_h^T Q'_h: one product over the sample's 2 L H rows, stack by stack (the
@@ -975,9 +1012,9 @@ class PairMemAttnFn(torch.autograd.Function):
         if need[1] and not self_att:
             dmem = torch.empty(B, Sk, dm, device=dev)   # both halves read the same memory
             grad_mem(dmem, (0, 0), Sk * dm, (False, True))
-        dQp = zeros(2 * R, H * dmp, dtype=_BF16, device=dev)
-        ops.gemm(PD, memb, L, dm, Sk, lda=ldpd, ldb=dmp, a_off=H * Skp, b_trans=True, batch=(B2, H), a_strides=(L * ldpd, Skp),
-                 b_strides=(Sk * dmp, 0), C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
+        if not fused:
+            ops.gemm(PD, memb, L, dm, Sk, lda=ldpd, ldb=dmp, a_off=H * Skp, b_trans=True, batch=(B2, H), a_strides=(L * ldpd, Skp),
+                     b_strides=(Sk * dmp, 0), C_bf16=dQp, ldcb=H * dmp, cb_strides=(L * H * dmp, dmp))
         # Q'_h = Q_h Wk_h
         dwk = SCRATCH.f32(2 * D, dm, device=dev, zero=not ops.gemm_overwrites(dk, dm, R, 2 * H))
         ops.gemm(Qb, dQp, dk, dm, R, lda=D, ldb=H * dmp, a_trans=True, b_trans=True, batch=(2, H), a_strides=(R * D, dk),

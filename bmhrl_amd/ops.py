@@ -152,6 +152,27 @@ def small_attention_bwd(dO, lddo, P, ldp, Q, K, V, dQ, dK, dV, mask, mask_sb, ma
                                                      stream()), "bmhrl_small_attention_bwd")
 
 
+def memory_attention_ok(L: int, Sk: int, dm: int) -> bool:
+    """shapes bmhrl_memory_attention serves (pure host query)"""
+    return bool(_lib.load().bmhrl_memory_attention_ok(L, Sk, dm))
+
+
+def cast_memory(x, y, y_t, B, Sk, dm, ldt):
+    """fp32 memory (B * Sk, dm) -> bf16 copy y (B * Sk, dm) and per-sample transposed copy y_t (B, dm, ldt), one launch"""
+    _need_cuda(x, y, y_t)
+    _lib.check(_lib.load().bmhrl_cast_memory(x.data_ptr(), y.data_ptr(), y_t.data_ptr(), B, Sk, dm, ldt, stream()), "bmhrl_cast_memory")
+
+
+def memory_attention(backward, X, x_off, ldx, mem, mem_t, ldt, PD, pd_row, pd_slot, Y, ldy, mask, mask_sb, n_mem, B2, H, L, Sk, dm,
+                     scale):
+    """few-query attention core over a memory, one launch (see bmhrl_memory_attention in include/bmhrl_hip.h)"""
+    _need_cuda(X, mem, mem_t, PD, Y)
+    _lib.check(_lib.load().bmhrl_memory_attention(int(backward), X.data_ptr() + 2 * x_off, ldx, mem.data_ptr(), Sk * dm,
+                                                  mem_t.data_ptr(), dm * ldt, ldt, PD.data_ptr(), pd_row, pd_slot, Y.data_ptr(), ldy,
+                                                  _p(mask), mask_sb, n_mem, B2, H, L, Sk, dm, scale, stream()),
+               "bmhrl_memory_attention")
+
+
 def attention_shared128_fwd(Qp, X, ctx, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, ldq, ldx, ldo):
     """absorbed-projection attention: Qp (B,Sq,H,128), X (B,Sk,128) shared by all heads -> ctx (B,Sq,H,128)"""
     _need_cuda(Qp, X, ctx)

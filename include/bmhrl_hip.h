@@ -159,6 +159,22 @@ int bmhrl_small_attention_bwd(const void* dO, int64_t lddo, const void* P, int32
 
 /* Row softmax of materialised scores (small-Sq path: caption self/cross attention, goal attention).
  * S fp32 (rows, lds) -> P bf16 (rows, ldp), cols valid columns; also writes nothing else. */
+/* Few-query attention over a long memory in the absorbed-projection form (functional.PairMemAttnFn; model/bm_hrl_agent.py:
+ * 87-101): L <= 32 queries of a (sample, head) against Sk <= 896 memory rows of width dm (multiple of 32, <= 1024), keys =
+ * values = the memory rows.  One launch per direction instead of GEMM + row kernel + GEMM:
+ *   forward  (backward = 0): P = softmax(scale X mem^T, -1e9 at masked keys) -> PD slot 0; Y = P mem          (X = Q', Y = context)
+ *   backward (backward = 1): dS = scale P (X mem^T - rowsum(P X mem^T)), 0 at masked keys -> PD slot 1; Y = dS mem (X = d context, Y = dQ')
+ * X / Y: bf16, row (b2 * L + q) * ld + h * dm; mem: bf16 (n_mem, Sk, dm) row-major, sample b2 reads memory b2 % n_mem; mem_t:
+ * the same memory transposed per sample, (n_mem, dm, ldt) with the columns [Sk, ldt) zero and ldt >= Sk rounded up to 16
+ * (bmhrl_cast_memory writes both from the fp32 memory in one pass); PD: bf16, element (b2 * L + q) * pd_row + slot * pd_slot +
+ * h * pad8(Sk) + key; mask: bytes, b2 * mask_sb + key.  bmhrl_memory_attention_ok: 1 when the shape is served. */
+int bmhrl_memory_attention_ok(int32_t L, int32_t Sk, int32_t dm);
+int bmhrl_cast_memory(const float* x, void* y, void* y_t, int32_t B, int32_t Sk, int32_t dm, int32_t ldt, bmhrl_stream_t stream);
+int bmhrl_memory_attention(int32_t backward, const void* X, int64_t ldx, const void* mem, int64_t mem_sb, const void* mem_t,
+                           int64_t mem_t_sb, int32_t ldt, void* PD, int64_t pd_row, int64_t pd_slot, void* Y, int64_t ldy,
+                           const uint8_t* mask, int64_t mask_sb, int32_t n_mem, int32_t B2, int32_t H, int32_t L, int32_t Sk,
+                           int32_t dm, float scale, bmhrl_stream_t stream);
+
 /* rows_per_group > 0: the bf16 rows (P here; P and dS in the backward) are laid out in groups of rows_per_group consecutive
  * rows, group g starting g * group_stride elements into the buffer (0: plain rows with the leading dimension) */
 int bmhrl_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int32_t cols, int32_t rows_per_group,

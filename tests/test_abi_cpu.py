@@ -20,7 +20,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/bmhrl_hip.h but not exported"
     assert set(_lib.PROTOTYPES) | {"bmhrl_hip_arch", "bmhrl_hip_abi_version", "bmhrl_layernorm_bwd_workspace",
-                                    "bmhrl_attention_shared128_bwd_workspace", "bmhrl_attention_max_keys", "bmhrl_gemm_splits", "bmhrl_small_attention_ok"} == set(syms)
+                                    "bmhrl_attention_shared128_bwd_workspace", "bmhrl_attention_max_keys", "bmhrl_gemm_splits", "bmhrl_small_attention_ok",
+                                    "bmhrl_memory_attention_ok"} == set(syms)
     assert lib.bmhrl_layernorm_bwd_workspace(4096, 1024) == 256 * 2 * 1024      # 4 rows per wave, 4 waves per block: 256 blocks
     assert lib.bmhrl_hip_arch() == b"gfx950"
     assert lib.bmhrl_hip_abi_version() == 11
@@ -29,6 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.bmhrl_gemm_splits(1024, 1024, 4096, 1) == 1 and lib.bmhrl_gemm_splits(128, 300, 480, 1) > 1
     assert lib.bmhrl_gemm_splits(0, 4, 4, 1) < 0
     assert lib.bmhrl_small_attention_ok(30, 30, 256) == 1 and lib.bmhrl_small_attention_ok(30, 33, 256) == 0
+    assert lib.bmhrl_memory_attention_ok(30, 800, 128) == 1 and lib.bmhrl_memory_attention_ok(30, 1024, 128) == 0
 
 
 def test_ops_refuse_cpu_tensors():
