@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(glob.glob(d + "/**/*_kernel_trace.csv", recursiv
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])) for r in rows)
 line = [l for l in open(log) if l.startswith('{"metric"')][-1]
 b = json.loads(line)
-print(f"bench line of this run: {b['ms_per_step']:.3f} ms/step under the tracer (graph launches become host-bound: 761 nodes are "
+print(f"bench line of this run: {b['ms_per_step']:.3f} ms/step under the tracer (graph launches become host-bound: the nodes are "
       f"submitted one by one), roofline.launch_us {b['roofline']['launch_us']:.2f}\n")
 last_adam = max(i for i, e in enumerate(ev) if "adam_" in e[2])
 tail = collections.defaultdict(list)
