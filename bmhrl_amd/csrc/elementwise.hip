@@ -684,7 +684,8 @@ __global__ void fusion_tail_fwd_kernel(const float* __restrict__ ca, const float
 constexpr int TAIL_RPB = 8, TAIL_MAXD = 512;    // (2 rows per wave, both in flight: 120 blocks per group at 480 rows; 4 rows one after
                                                 //  the other ran 22-27 us inside the step, 64 rows per block 15 us on 16 CUs)
 template <int NC>
-__global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ ca,
+__global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __restrict__ dout0, const float* __restrict__ dout1,
+                                                              long ldd0, long ldd1, const float* __restrict__ ca,
                                                               const float* __restrict__ cv, const float* __restrict__ stats,
                                                               const TailTable T, long rows_per_group, int n_groups, int D,
                                                               float* __restrict__ dca, float* __restrict__ dcv) {
@@ -694,6 +695,9 @@ __global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = blockIdx.y;
   const bmhrl_fusion_tail_params& P = T.g[grp];
+  // the incoming gradient of a group: its own base and row stride (the two stacks' outputs are consumed by different heads)
+  const float* __restrict__ dout = grp ? dout1 : dout0;
+  const long ldd = grp ? ldd1 : ldd0;
   const float a = P.a_v[0], gate = gate_of(P.a_v);
   float dga[NC], dba[NC], dgv[NC], dbv[NC], ga[NC], gv[NC], ba[NC], bv[NC];
 #pragma unroll
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __res
   static_assert(TAIL_RPB == 8, "a wave owns rows w and w + 4 of the block: both rows' loads are requested before either is reduced");
   struct RowIn { float ma, ra, mv, rv, xa[NC], xv[NC], d[NC]; };
   auto load_row = [&](const long r, RowIn& R) {
-    const long row = grp * rows_per_group + (r < r_end ? r : r_end - 1);
+    const long rg = r < r_end ? r : r_end - 1, row = grp * rows_per_group + rg;
     R.ma = stats[row]; R.ra = stats[rows + row]; R.mv = stats[2 * rows + row]; R.rv = stats[3 * rows + row];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(256) void fusion_tail_bwd_kernel(const float* __res
       const bool in = c < D;
       R.xa[i] = in ? ca[row * D + c] : 0.f;
       R.xv[i] = in ? cv[row * D + c] : 0.f;
-      R.d[i] = in ? dout[row * D + c] : 0.f;
+      R.d[i] = in ? dout[rg * ldd + c] : 0.f;
     }
   };
   RowIn R2[2];
@@ -1255,15 +1259,19 @@ extern "C" int bmhrl_fusion_tail_fwd(const float* ca, const float* cv, const bmh
   return hip_status(hipGetLastError());
 }
 
-extern "C" int bmhrl_fusion_tail_bwd(const float* dout, const float* ca, const float* cv, const float* stats,
-                                     const bmhrl_fusion_tail_params* groups, int32_t n_groups, int64_t rows_per_group, int32_t D,
-                                     float* dca, float* dcv, bmhrl_stream_t stream) {
+extern "C" int bmhrl_fusion_tail_bwd(const float* dout, const float* dout1, int64_t ldd0, int64_t ldd1, const float* ca,
+                                     const float* cv, const float* stats, const bmhrl_fusion_tail_params* groups, int32_t n_groups,
+                                     int64_t rows_per_group, int32_t D, float* dca, float* dcv, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(dout && ca && cv && stats && dca && dcv && rows_per_group > 0 && D > 0 && D <= TAIL_MAXD);
   TailTable T;
   if (int rc = tail_table(groups, n_groups, true, T)) return rc;
+  if (ldd0 <= 0) ldd0 = D;
+  if (ldd1 <= 0) ldd1 = ldd0;
+  if (!dout1) dout1 = dout + rows_per_group * ldd0;          // (one tensor holding both groups back to back)
+  BMHRL_CHECK_ARG(ldd0 >= D && ldd1 >= D);
   dim3 grid((unsigned)((rows_per_group + TAIL_RPB - 1) / TAIL_RPB), (unsigned)n_groups), block(256);
-  if (D <= 320) hipLaunchKernelGGL(fusion_tail_bwd_kernel<5>, grid, block, 0, S_(stream), dout, ca, cv, stats, T, (long)rows_per_group, n_groups, D, dca, dcv);
-  else hipLaunchKernelGGL(fusion_tail_bwd_kernel<8>, grid, block, 0, S_(stream), dout, ca, cv, stats, T, (long)rows_per_group, n_groups, D, dca, dcv);
+  if (D <= 320) hipLaunchKernelGGL(fusion_tail_bwd_kernel<5>, grid, block, 0, S_(stream), dout, dout1, (long)ldd0, (long)ldd1, ca, cv, stats, T, (long)rows_per_group, n_groups, D, dca, dcv);
+  else hipLaunchKernelGGL(fusion_tail_bwd_kernel<8>, grid, block, 0, S_(stream), dout, dout1, (long)ldd0, (long)ldd1, ca, cv, stats, T, (long)rows_per_group, n_groups, D, dca, dcv);
   return hip_status(hipGetLastError());
 }
 

@@ -309,13 +309,20 @@ class StepScratch:
         key = (t.data_ptr(), t._version, rows, cols, copies)
         if self.armed:
             hit = self.memo.get(key)
-            if hit is not None and hit[0]() is t:
+            if hit is not None and hit[0]() is not None:       # (same address + version as a tensor that is still alive)
                 return hit[1]
         buf = self.bf16(copies * rows, cols, t.device)
         ops.cast_bf16_copies(t.contiguous(), cols, buf, buf.shape[1], rows, cols, copies, rows * buf.shape[1])
         if self.armed:
             self.memo[key] = (weakref.ref(t), buf)
         return buf
+
+    def offer_bf16(self, t: torch.Tensor, rows: int, cols: int, buf: torch.Tensor):
+        """the producer of the fp32 tensor t wrote its bf16 copy `buf` ((rows, pad8(cols)), from the same epilogue): later
+        memo_bf16(t, rows, cols) calls of this step take it instead of casting (the self-attention outputs of an encoder layer
+        are the other modality's memory)"""
+        if self.armed:
+            self.memo[(t.data_ptr(), t._version, rows, cols, 1)] = (weakref.ref(t), buf)
 
     def memo_mem(self, t: torch.Tensor, B: int, Sk: int, dm: int):
         """(bf16 copy (B * Sk, dm), per-sample transposed bf16 copy (B, dm, ldt), ldt) of the fp32 memory t (B, Sk, dm) for
@@ -524,7 +531,10 @@ class MHAFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, kv_in, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop, residual, kv_cache=None):
+    def forward(ctx, x, kv_in, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop, residual, kv_cache=None,
+                emit_bf16=False):
+        """emit_bf16: the output's bf16 copy leaves the last GEMM's epilogue too and is offered to the step's memo
+        (StepScratch.offer_bf16): the consumer that takes this output as its attention memory finds it there"""
         dev = x.device
         B, Sq, dq = x.shape
         D = wq.shape[0]
@@ -565,8 +575,7 @@ class MHAFn(torch.autograd.Function):
             kvb = None
             if KV is None:
                 kv_in = kv_in.contiguous()
-                kvb = SCRATCH.bf16(rows_k, dkv, dev)
-                ops.cast_bf16(kv_in, dkv, kvb, kvb.shape[1], rows_k, dkv)
+                kvb = SCRATCH.memo_bf16(kv_in, rows_k, dkv)      # (the producer may have offered it: offer_bf16)
                 w_kv = SHADOWS.weight(wk, wv)
                 KV = torch.empty(rows_k, 2 * D, dtype=_BF16, device=dev)
                 ops.gemm(kvb, w_kv, rows_k, 2 * D, dkv, lda=kvb.shape[1], ldb=w_kv.shape[1], C_bf16=KV, ldcb=2 * D,
@@ -578,8 +587,12 @@ class MHAFn(torch.autograd.Function):
         Ob, stats = _attn_core_fwd(Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ldk, m8, msb, msq, B, H, Sq, Sk, dk, p_drop, s_attn)
         w_o = SHADOWS.weight(wo)
         y = torch.empty(B, Sq, dq, device=dev)
+        yb = SCRATCH.bf16(rows_q, dq, dev) if (emit_bf16 and SCRATCH.armed) else None
         ops.gemm(Ob, w_o, rows_q, dq, D, lda=D, ldb=w_o.shape[1], C_f32=y, ldc=dq, bias=bo.detach(),
-                 residual=x if residual else None, ldr=dq, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+                 residual=x if residual else None, ldr=dq, dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev,
+                 C_bf16=yb, ldcb=yb.shape[1] if yb is not None else 0)
+        if yb is not None:
+            SCRATCH.offer_bf16(y, rows_q, dq, yb)
         ctx.save_for_backward(x, ln_w, mean, rstd, xb, kvb, Qb, Kb, Ob, m8, *stats[1:], wq, wk, wv, wo)
         ctx.cfg = (B, H, Sq, Sk, dq, dkv, D, dk, p_drop, residual, self_att, has_ln, stats[0], msb, msq, s_attn, s_res,
                    q_off, k_off, v_off, ldq, ldk)
@@ -677,7 +690,7 @@ class MHAFn(torch.autograd.Function):
             dx = dxn.view(B, Sq, dq)
             if residual:
                 dx = dx + dy
-        return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None, None)
+        return (dx, dkv_in, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None, None, None)
 
 
 # fused (flash-style) backward of the head-dimension-128 attention; BMHRL_FUSED_ATTN_BWD=0 keeps the materialised P / dS GEMMs
@@ -701,7 +714,7 @@ class MemAttnFn(torch.autograd.Function):
     are laid out (B, L, H, .) so that sums over heads are plain GEMMs with K = L*H."""
 
     @staticmethod
-    def forward(ctx, x, mem, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop):
+    def forward(ctx, x, mem, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_drop, emit_bf16=False):
         # mem is None: self attention -- the memory is LN(x) itself (keys / values of the reference's self attention
         # are projections of the normalised input), and its gradient joins the one of the query path
         dev = x.device
@@ -757,8 +770,11 @@ class MemAttnFn(torch.autograd.Function):
                  b_strides=(0, dk * w_v.shape[1]), C_bf16=Ob, ldcb=D, cb_strides=(0, dk), bias=bv.detach(), bias_sb2=dk,
                  dropout_p=p_drop, seed=s_attn, seed_dev=SEEDS.dev, drop_strides=(0, dk, D))
         y = torch.empty(B, L, dq, device=dev)
+        yb = SCRATCH.bf16(rows, dq, dev) if (emit_bf16 and SCRATCH.armed) else None      # (see MHAFn.forward)
         ops.gemm(Ob, w_o, rows, dq, D, lda=D, ldb=w_o.shape[1], C_f32=y, ldc=dq, bias=bo.detach(), residual=x, ldr=dq,
-                 dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev)
+                 dropout_p=p_drop, seed=s_res, seed_dev=SEEDS.dev, C_bf16=yb, ldcb=yb.shape[1] if yb is not None else 0)
+        if yb is not None:
+            SCRATCH.offer_bf16(y, rows, dq, yb)
         ctx.save_for_backward(x, ln_w, mean, rstd, xb, memb, Qb, Qp, Cx, Ob, wq, wk, wv, wo, m8, *stats)
         ctx.cfg = (B, L, Sk, dq, dm, D, H, dk, p_drop, s_attn, s_res, self_att, flash, msb, msq)
         return y
@@ -868,7 +884,7 @@ class MemAttnFn(torch.autograd.Function):
         dlnw = SCRATCH.f32(dq, device=dev) if need[2] else None
         dlnb = SCRATCH.f32(dq, device=dev) if need[3] else None
         ops.layernorm_bwd(dxn, x, ln_w, mean, rstd, dx, dy, dlnw, dlnb, rows, dq)
-        return (dx, dmem, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None)
+        return (dx, dmem, dlnw, dlnb, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, None, None)
 
 
 class PairMemAttnFn(torch.autograd.Function):
@@ -1200,10 +1216,12 @@ class FusionTailFn(torch.autograd.Function):
     """g * normCV(cv) + (1 - g) * normCA(ca), g = sigmoid(clamp(a_v, -2, 2)) -- the tail of BMFusionLayer.forward
     (model/bm_hrl_agent.py:107-114) as ONE launch forward and ONE backward (two LayerNorms + the gate; it was five / six).
     cv, ca: (..., D) of one stack, or (2, B, L, D) of the paired stacks with `groups` = 2 parameter sets
-    (normCA.weight, normCA.bias, normCV.weight, normCV.bias, a_v) x groups, passed flat."""
+    (normCA.weight, normCA.bias, normCV.weight, normCV.bias, a_v) x groups, passed flat.  unstack (paired form): the two
+    stacks' results are returned as two tensors -- after the last layer they go to different heads, and the backward then reads
+    the two incoming gradients where they are (two select-backward fills, two copies and an add otherwise)."""
 
     @staticmethod
-    def forward(ctx, cv, ca, groups, *params):
+    def forward(ctx, cv, ca, groups, unstack, *params):
         D = cv.shape[-1]
         rows = cv.numel() // D
         assert len(params) == 5 * groups and rows % groups == 0
@@ -1214,10 +1232,11 @@ class FusionTailFn(torch.autograd.Function):
         ops.fusion_tail_fwd(ca, cv, gs, rows // groups, D, out, stats)
         ctx.save_for_backward(cv, ca, stats, *params)
         ctx.groups = groups
-        return out
+        ctx.unstack = bool(unstack) and groups == 2 and out.shape[0] == 2
+        return (out[0], out[1]) if ctx.unstack else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         cv, ca, stats = ctx.saved_tensors[:3]
         params = ctx.saved_tensors[3:]
         groups = ctx.groups
@@ -1231,10 +1250,21 @@ class FusionTailFn(torch.autograd.Function):
         for i in range(groups):
             g = []
             for j in range(5):
-                g.append(SCRATCH.f32(1 if j == 4 else D, device=dev) if need[3 + 5 * i + j] else None)
+                g.append(SCRATCH.f32(1 if j == 4 else D, device=dev) if need[4 + 5 * i + j] else None)
             grads.append(tuple(g))
-        ops.fusion_tail_bwd(dout.contiguous(), ca, cv, stats, gs, grads, rows // groups, D, dca, dcv)
-        return (dcv, dca, None) + tuple(t for g in grads for t in g)
+        if ctx.unstack:
+            halves = []
+            for g in douts:                  # a stack nothing was computed from (frozen phase): zero; rows may be strided views
+                if g is None:
+                    g = torch.zeros(rows // 2, D, device=dev)
+                elif g.stride(-1) != 1 or g.dim() < 2 or any(g.stride(i) != g.stride(i + 1) * g.shape[i + 1] for i in range(g.dim() - 2)):
+                    g = g.contiguous()
+                halves.append(g)
+            ops.fusion_tail_bwd(halves[0], ca, cv, stats, gs, grads, rows // groups, D, dca, dcv, dout1=halves[1],
+                                ldd0=halves[0].stride(-2), ldd1=halves[1].stride(-2))
+        else:
+            ops.fusion_tail_bwd(douts[0].contiguous(), ca, cv, stats, gs, grads, rows // groups, D, dca, dcv)
+        return (dcv, dca, None, None) + tuple(t for g in grads for t in g)
 
 
 class AttnCoreFn(torch.autograd.Function):

@@ -79,8 +79,8 @@ class BMEncoderLayer(nn.Module):
     def _self_att_M2(self, M2, M2_mask):
         att, norm = self.self_att_M2, self.res_layers_M2[0].norm
         if self.absorb_narrow_memory and M2.is_cuda and att.d_model_K == 128 and att.d_k > 128:   # (the fused kernel's width)
-            return att.fused_memory(M2, None, M2_mask, norm)
-        return att.fused(M2, None, M2_mask, norm, residual=True)
+            return att.fused_memory(M2, None, M2_mask, norm, emit_bf16=True)
+        return att.fused(M2, None, M2_mask, norm, residual=True, emit_bf16=True)
 
     def _cross_M1(self, M1, M2, M2_mask):
         att, norm = self.bi_modal_att_M1, self.res_layers_M1[1].norm
@@ -92,7 +92,7 @@ class BMEncoderLayer(nn.Module):
         M1, M2 = x
         M1_mask, M2_mask = masks
         if not (M1.is_cuda and self.modality_side_stream):
-            M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
+            M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True, emit_bf16=True)
             M2 = self._self_att_M2(M2, M2_mask)
             M1m2 = self._cross_M1(M1, M2, M2_mask)
             M2m1 = self.bi_modal_att_M2.fused(M2, M1, M1_mask, self.res_layers_M2[1].norm, residual=True)
@@ -103,7 +103,9 @@ class BMEncoderLayer(nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             M2 = self._self_att_M2(M2, M2_mask)
-        M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True)
+        # (emit_bf16: each self-attention output is the other modality's attention memory -- its bf16 copy leaves the epilogue
+        #  that produces it instead of a cast launch on the consumer's chain)
+        M1 = self.self_att_M1.fused(M1, None, M1_mask, self.res_layers_M1[0].norm, residual=True, emit_bf16=True)
         main.wait_stream(side)          # both self-attention outputs are needed by both cross attentions
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -176,7 +178,7 @@ class BMFusionLayer(nn.Module):
     def _tail(self, Cv, Ca):
         """reference :107-114"""
         if self.fused_tail and Cv.is_cuda and Cv.shape[-1] <= 512:
-            return FusionTailFn.apply(Cv, Ca, 1, *self._tail_params())
+            return FusionTailFn.apply(Cv, Ca, 1, False, *self._tail_params())
         Ca = LayerNormFn.apply(Ca, self.normCA.weight, self.normCA.bias)
         Cv = LayerNormFn.apply(Cv, self.normCV.weight, self.normCV.bias)
         return GateFn.apply(Cv, Ca, self.a_v_constant)
@@ -206,7 +208,8 @@ def fusion_pair(fw, fm, C, Av, Va, masks):
     else:
         cm2, am2, vm2 = (torch.cat([masks[k], masks[k]]) for k in ('C_mask', 'A_mask', 'V_mask'))
     fused_tail = BMFusionLayer.fused_tail and C.shape[-1] <= 512
-    for lw, lm in zip(fw.decoder.layers, fm.decoder.layers):
+    n_layers = len(fw.decoder.layers)
+    for li, (lw, lm) in enumerate(zip(fw.decoder.layers, fm.decoder.layers)):
         H = lw.self_att.H
         p = lw.self_att.dout_p if lw.training else 0.0
         C2 = PairSelfAttnFn.apply(C2, cm2, H, p, *_att_params(lw.self_att, lw.res_layer_self_att.norm),
@@ -230,7 +233,8 @@ def fusion_pair(fw, fm, C, Av, Va, masks):
         if side is not None:
             main.wait_stream(side)
         if fused_tail:       # both stacks' normCA + normCV + gate: one launch (it was six)
-            C2 = FusionTailFn.apply(Cv2, Ca2, 2, *lw._tail_params(), *lm._tail_params())
+            # (after the last layer the two stacks part: returned as two tensors, see FusionTailFn)
+            C2 = FusionTailFn.apply(Cv2, Ca2, 2, li == n_layers - 1, *lw._tail_params(), *lm._tail_params())
         else:
             C2 = PairGateFn.apply(Cv2, Ca2, lw.a_v_constant, lm.a_v_constant)
     return C2[0], C2[1]

@@ -26,7 +26,7 @@ class MultiheadedAttention(nn.Module):
         return (self.linear_Q2d.weight, self.linear_Q2d.bias, self.linear_K2d.weight, self.linear_K2d.bias,
                 self.linear_V2d.weight, self.linear_V2d.bias, self.linear_d2Q.weight, self.linear_d2Q.bias)
 
-    def fused(self, x, kv, mask, norm=None, residual=False, res_dropout=None, kv_cache=None):
+    def fused(self, x, kv, mask, norm=None, residual=False, res_dropout=None, kv_cache=None, emit_bf16=False):
         """[x +] drop(MHA(LN?(x), kv, kv)).  kv=None -> self attention on the normalised x.
         The reference applies dout_p twice (attention output, residual branch); both use this module's rate
         unless the residual connection's own rate is given."""
@@ -35,13 +35,13 @@ class MultiheadedAttention(nn.Module):
         p = self.dout_p if self.training else 0.0
         ln_w = norm.weight if norm is not None else None
         ln_b = norm.bias if norm is not None else None
-        return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual, kv_cache)
+        return MHAFn.apply(x, kv, ln_w, ln_b, *self._params(), mask, self.H, p, residual, kv_cache, emit_bf16)
 
-    def fused_memory(self, x, mem, mask, norm):
+    def fused_memory(self, x, mem, mask, norm, emit_bf16=False):
         """x + drop(MHA(LN(x), mem, mem)) for few queries against a long memory: same function as fused(x, mem, ...,
         residual=True), evaluated without ever projecting the memory (functional.MemAttnFn)."""
         p = self.dout_p if self.training else 0.0
-        return MemAttnFn.apply(x, mem, norm.weight, norm.bias, *self._params(), mask, self.H, p)   # mem None: self attention
+        return MemAttnFn.apply(x, mem, norm.weight, norm.bias, *self._params(), mask, self.H, p, emit_bf16)   # mem None: self attention
 
     def forward(self, Q, K, V, mask, causal=False):
         """Reference signature: Q (B,Sq,Dq), K (B,Sk,Dk), V (B,Sk,Dv), mask (B,1,Sk) or (B,Sq,Sk) -> (B,Sq,Dq).

@@ -359,13 +359,14 @@ def fusion_tail_fwd(ca, cv, groups, rows_per_group, D, out, stats):
                                                  out.data_ptr(), stats.data_ptr(), stream()), "bmhrl_fusion_tail_fwd")
 
 
-def fusion_tail_bwd(dout, ca, cv, stats, groups, grads, rows_per_group, D, dca, dcv):
-    """grads: per group (dgamma_ca, dbeta_ca, dgamma_cv, dbeta_cv, da_v), zeroed fp32 tensors or None"""
+def fusion_tail_bwd(dout, ca, cv, stats, groups, grads, rows_per_group, D, dca, dcv, dout1=None, ldd0=0, ldd1=0):
+    """grads: per group (dgamma_ca, dbeta_ca, dgamma_cv, dbeta_cv, da_v), zeroed fp32 tensors or None.
+    dout: gradient of group 0's rows (row stride ldd0, 0 = D); dout1: of group 1's (None: behind group 0's in dout)"""
     _need_cuda(dout, ca, cv, stats, dca, dcv)
     arr = _tail_groups(groups, grads)
-    _lib.check(_lib.load().bmhrl_fusion_tail_bwd(dout.data_ptr(), ca.data_ptr(), cv.data_ptr(), stats.data_ptr(), C.cast(arr, C.c_void_p),
-                                                 len(groups), rows_per_group, D, dca.data_ptr(), dcv.data_ptr(), stream()),
-               "bmhrl_fusion_tail_bwd")
+    _lib.check(_lib.load().bmhrl_fusion_tail_bwd(dout.data_ptr(), _p(dout1), ldd0, ldd1, ca.data_ptr(), cv.data_ptr(), stats.data_ptr(),
+                                                 C.cast(arr, C.c_void_p), len(groups), rows_per_group, D, dca.data_ptr(),
+                                                 dcv.data_ptr(), stream()), "bmhrl_fusion_tail_bwd")
 
 
 def expand_goals_index(seg, src, B, L):

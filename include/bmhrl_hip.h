@@ -298,9 +298,11 @@ typedef struct bmhrl_fusion_tail_params {
 } bmhrl_fusion_tail_params;
 int bmhrl_fusion_tail_fwd(const float* ca, const float* cv, const bmhrl_fusion_tail_params* groups, int32_t n_groups,
                           int64_t rows_per_group, int32_t D, float* out, float* stats, bmhrl_stream_t stream);
-int bmhrl_fusion_tail_bwd(const float* dout, const float* ca, const float* cv, const float* stats,
-                          const bmhrl_fusion_tail_params* groups, int32_t n_groups, int64_t rows_per_group, int32_t D,
-                          float* dca, float* dcv, bmhrl_stream_t stream);
+/* dout: the incoming gradient of group 0 (row stride ldd0, <= 0: D); dout1: of group 1 (row stride ldd1; NULL: the rows
+ * behind group 0's in the same tensor) -- the two stacks' outputs are consumed by different heads */
+int bmhrl_fusion_tail_bwd(const float* dout, const float* dout1, int64_t ldd0, int64_t ldd1, const float* ca, const float* cv,
+                          const float* stats, const bmhrl_fusion_tail_params* groups, int32_t n_groups, int64_t rows_per_group,
+                          int32_t D, float* dca, float* dcv, bmhrl_stream_t stream);
 
 /* Manager.expand_goals (K8), model/bm_hrl_agent.py:415-429: src[row] = row of goals_in copied to (b,l), or -1 = zero.
  * bmhrl_expand_goals_index builds the (B*L) int32 source map from the segment labels with the reference's

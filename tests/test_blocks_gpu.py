@@ -435,7 +435,7 @@ def test_fusion_tail_one_launch_equals_norms_and_gate(dev):
             params += [leaf(D, g=g, dev=dev), leaf(D, scale=0.1, g=g, dev=dev), leaf(D, g=g, dev=dev), leaf(D, scale=0.1, g=g, dev=dev),
                        torch.tensor([a0], device=dev, requires_grad=True)]
         dout = torch.randn(2, B, L, D, generator=g).to(dev)
-        out = FusionTailFn.apply(cv, ca, 2, *params)
+        out = FusionTailFn.apply(cv, ca, 2, False, *params)
         out.backward(dout)
         got = [t.grad.clone() for t in [cv, ca] + params]
         for t in [cv, ca] + params:
@@ -452,5 +452,20 @@ def test_fusion_tail_one_launch_equals_norms_and_gate(dev):
             assert rel(aa, t.grad, floor=1e-4) < 2e-4, (D, tuple(t.shape))
         assert float(params[9].grad.abs().max()) == 0.0 and float(got[2 + 9].abs().max()) == 0.0
         # one group == the same call on one stack
-        one = FusionTailFn.apply(cv[0].detach(), ca[0].detach(), 1, *[t.detach() for t in params[:5]])
+        one = FusionTailFn.apply(cv[0].detach(), ca[0].detach(), 1, False, *[t.detach() for t in params[:5]])
         assert torch.equal(one, out[0].detach())
+        # unstacked form: two outputs whose gradients arrive separately -- one of them a strided view (as the worker head's
+        # d cat[x, gc][..., :D] is), the other missing (a frozen stack): same gradients as the stacked form with that dout
+        for t in [cv, ca] + params:
+            t.grad = None
+        ow, om = FusionTailFn.apply(cv, ca, 2, True, *params)
+        assert torch.equal(ow, out[0].detach()) and torch.equal(om, out[1].detach())
+        wide = torch.randn(B, L, D + 24, generator=g).to(dev)
+        (ow * wide[..., :D]).sum().backward()
+        got2 = [t.grad.clone() for t in [cv, ca] + params]
+        for t in [cv, ca] + params:
+            t.grad = None
+        out2 = FusionTailFn.apply(cv, ca, 2, False, *params)
+        out2.backward(torch.stack([wide[..., :D], torch.zeros(B, L, D, device=dev)]))
+        for aa, t in zip(got2, [cv, ca] + params):
+            assert rel(aa, t.grad, floor=1e-4) < 1e-5, (D, tuple(t.shape))
