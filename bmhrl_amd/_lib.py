@@ -88,7 +88,7 @@ PROTOTYPES = {
     "bmhrl_cast_bf16_copies": [ptr, i64, ptr, i64, i64, i32, i32, i64, ptr],
     "bmhrl_gate_fwd": [ptr, ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_gate_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
-    "bmhrl_fusion_tail_fwd": [ptr, ptr, ptr, i32, i64, i32, ptr, ptr, ptr],
+    "bmhrl_fusion_tail_fwd": [ptr, ptr, ptr, i32, i64, i32, ptr, ptr, ptr, i64, ptr],
     "bmhrl_fusion_tail_bwd": [ptr, ptr, i64, i64, ptr, ptr, ptr, ptr, i32, i64, i32, ptr, ptr, ptr],
     "bmhrl_expand_goals_index": [ptr, ptr, i32, i32, ptr],
     "bmhrl_gather_rows": [ptr, ptr, ptr, ptr, i64, i64, i32, ptr],

@@ -636,7 +636,8 @@ struct TailTable {
 };
 template <int NC>
 __global__ void fusion_tail_fwd_kernel(const float* __restrict__ ca, const float* __restrict__ cv, const TailTable T, long rows_per_group,
-                                       int n_groups, int D, float* __restrict__ out, float* __restrict__ stats) {
+                                       int n_groups, int D, float* __restrict__ out, float* __restrict__ stats,
+                                       bf16_t* __restrict__ out_bf16, long ldob) {
   const long rows = rows_per_group * n_groups;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -673,7 +674,9 @@ __global__ void fusion_tail_fwd_kernel(const float* __restrict__ ca, const float
     if (c < D) {
       const float ya = (xa[i] - ma) * ra * P.gamma_ca[c] + P.beta_ca[c];
       const float yv = (xv[i] - mv) * rv * P.gamma_cv[c] + P.beta_cv[c];
-      out[row * D + c] = gate * yv + (1.f - gate) * ya;
+      const float o = gate * yv + (1.f - gate) * ya;
+      out[row * D + c] = o;
+      if (out_bf16) out_bf16[row * ldob + c] = (bf16_t)o;       // (the next blocks' GEMM operand: no cast launch)
     }
   }
 }
@@ -1248,14 +1251,16 @@ static int tail_table(const bmhrl_fusion_tail_params* groups, int32_t n_groups, 
 }
 
 extern "C" int bmhrl_fusion_tail_fwd(const float* ca, const float* cv, const bmhrl_fusion_tail_params* groups, int32_t n_groups,
-                                     int64_t rows_per_group, int32_t D, float* out, float* stats, bmhrl_stream_t stream) {
+                                     int64_t rows_per_group, int32_t D, float* out, float* stats, void* out_bf16, int64_t ldob,
+                                     bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(ca && cv && out && stats && rows_per_group > 0 && D > 0 && D <= TAIL_MAXD);
   TailTable T;
   if (int rc = tail_table(groups, n_groups, false, T)) return rc;
   const long rows = rows_per_group * n_groups;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (D <= 320) hipLaunchKernelGGL(fusion_tail_fwd_kernel<5>, grid, block, 0, S_(stream), ca, cv, T, (long)rows_per_group, n_groups, D, out, stats);
-  else hipLaunchKernelGGL(fusion_tail_fwd_kernel<8>, grid, block, 0, S_(stream), ca, cv, T, (long)rows_per_group, n_groups, D, out, stats);
+  BMHRL_CHECK_ARG(!out_bf16 || ldob >= D);
+  if (D <= 320) hipLaunchKernelGGL(fusion_tail_fwd_kernel<5>, grid, block, 0, S_(stream), ca, cv, T, (long)rows_per_group, n_groups, D, out, stats, (bf16_t*)out_bf16, (long)ldob);
+  else hipLaunchKernelGGL(fusion_tail_fwd_kernel<8>, grid, block, 0, S_(stream), ca, cv, T, (long)rows_per_group, n_groups, D, out, stats, (bf16_t*)out_bf16, (long)ldob);
   return hip_status(hipGetLastError());
 }
 

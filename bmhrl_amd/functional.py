@@ -222,6 +222,7 @@ class StepScratch:
         self.spill_raw = 0
         self.cursor = {}
         self.memo = {}
+        self.memo_hits = 0           # memo_bf16 calls served without a cast (a producer's offer or an earlier call)
         self._zeroing = None
 
     # (the buffers live in the bound state)
@@ -310,6 +311,7 @@ class StepScratch:
         if self.armed:
             hit = self.memo.get(key)
             if hit is not None and hit[0]() is not None:       # (same address + version as a tensor that is still alive)
+                self.memo_hits += 1
                 return hit[1]
         buf = self.bf16(copies * rows, cols, t.device)
         ops.cast_bf16_copies(t.contiguous(), cols, buf, buf.shape[1], rows, cols, copies, rows * buf.shape[1])
@@ -1229,11 +1231,21 @@ class FusionTailFn(torch.autograd.Function):
         out = torch.empty_like(cv)
         stats = torch.empty(4, rows, device=cv.device)
         gs = [tuple(t.detach() for t in params[5 * i:5 * i + 5]) for i in range(groups)]
-        ops.fusion_tail_fwd(ca, cv, gs, rows // groups, D, out, stats)
+        ctx.unstack = bool(unstack) and groups == 2 and out.shape[0] == 2
+        # the parted outputs feed projections next (manager linear, goal attention, value heads): their bf16 operands
+        # leave this launch too and wait in the step's memo
+        ob = SCRATCH.bf16(rows, D, cv.device) if (ctx.unstack and SCRATCH.armed) else None
+        ops.fusion_tail_fwd(ca, cv, gs, rows // groups, D, out, stats, ob, ob.shape[1] if ob is not None else 0)
         ctx.save_for_backward(cv, ca, stats, *params)
         ctx.groups = groups
-        ctx.unstack = bool(unstack) and groups == 2 and out.shape[0] == 2
-        return (out[0], out[1]) if ctx.unstack else out
+        if not ctx.unstack:
+            return out
+        o0, o1 = out[0], out[1]
+        if ob is not None:
+            h = rows // 2
+            SCRATCH.offer_bf16(o0, h, D, ob[:h])
+            SCRATCH.offer_bf16(o1, h, D, ob[h:])
+        return o0, o1
 
     @staticmethod
     def backward(ctx, *douts):
@@ -1381,8 +1393,7 @@ class LinearFn(torch.autograd.Function):
         rows = x.numel() // K
         N = w.shape[0]
         x2 = x.contiguous().view(rows, K)
-        xb = SCRATCH.bf16(rows, K, dev)
-        ops.cast_bf16(x2, K, xb, xb.shape[1], rows, K)
+        xb = SCRATCH.memo_bf16(x2, rows, K)              # (its producer may have offered the bf16 copy: StepScratch.offer_bf16)
         wb = SHADOWS.weight(w)
         y = torch.empty(rows, N, device=dev)
         seed = SEEDS.next()

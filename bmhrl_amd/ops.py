@@ -351,12 +351,13 @@ def _tail_groups(groups, grads=None):
     return arr
 
 
-def fusion_tail_fwd(ca, cv, groups, rows_per_group, D, out, stats):
-    """out = g * LN_CV(cv) + (1 - g) * LN_CA(ca); groups: list (1 or 2) of (gamma_ca, beta_ca, gamma_cv, beta_cv, a_v)"""
+def fusion_tail_fwd(ca, cv, groups, rows_per_group, D, out, stats, out_bf16=None, ldob=0):
+    """out = g * LN_CV(cv) + (1 - g) * LN_CA(ca); groups: list (1 or 2) of (gamma_ca, beta_ca, gamma_cv, beta_cv, a_v);
+    out_bf16 (rows, ldob): the same values in bf16 as well"""
     _need_cuda(ca, cv, out, stats)
     arr = _tail_groups(groups)
     _lib.check(_lib.load().bmhrl_fusion_tail_fwd(ca.data_ptr(), cv.data_ptr(), C.cast(arr, C.c_void_p), len(groups), rows_per_group, D,
-                                                 out.data_ptr(), stats.data_ptr(), stream()), "bmhrl_fusion_tail_fwd")
+                                                 out.data_ptr(), stats.data_ptr(), _p(out_bf16), ldob, stream()), "bmhrl_fusion_tail_fwd")
 
 
 def fusion_tail_bwd(dout, ca, cv, stats, groups, grads, rows_per_group, D, dca, dcv, dout1=None, ldd0=0, ldd1=0):

@@ -296,8 +296,10 @@ typedef struct bmhrl_fusion_tail_params {
   const float* gamma_ca; const float* beta_ca; const float* gamma_cv; const float* beta_cv; const float* a_v;
   float* dgamma_ca; float* dbeta_ca; float* dgamma_cv; float* dbeta_cv; float* da_v;          /* backward only */
 } bmhrl_fusion_tail_params;
+/* out_bf16 (optional, row stride ldob >= D): the result in bf16 as well -- the operand of the blocks that consume it */
 int bmhrl_fusion_tail_fwd(const float* ca, const float* cv, const bmhrl_fusion_tail_params* groups, int32_t n_groups,
-                          int64_t rows_per_group, int32_t D, float* out, float* stats, bmhrl_stream_t stream);
+                          int64_t rows_per_group, int32_t D, float* out, float* stats, void* out_bf16, int64_t ldob,
+                          bmhrl_stream_t stream);
 /* dout: the incoming gradient of group 0 (row stride ldd0, <= 0: D); dout1: of group 1 (row stride ldd1; NULL: the rows
  * behind group 0's in the same tensor) -- the two stacks' outputs are consumed by different heads */
 int bmhrl_fusion_tail_bwd(const float* dout, const float* dout1, int64_t ldd0, int64_t ldd1, const float* ca, const float* cv,
