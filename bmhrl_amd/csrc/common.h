@@ -45,6 +45,15 @@ static inline void bmhrl_arg_fail(const char* cond, const char* file, int line) 
 
 static inline int hip_status(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
+// BMHRL_DETERMINISTIC=1: every sum whose order depends on the scheduling of fp32 atomics takes an ordered path instead --
+// no K split in the GEMMs, column sums / LayerNorm parameter gradients / the gate's scalar through one owner per address,
+// embedding and goal scatter gradients row by row.  Same arithmetic up to the order of additions; slower (the step measured
+// below in DESIGN.md); two runs of the same step then agree bit for bit (tests/test_split_backward_gpu.py).
+static inline bool bmhrl_deterministic() {
+  static const bool on = getenv("BMHRL_DETERMINISTIC") != nullptr && atoi(getenv("BMHRL_DETERMINISTIC")) != 0;
+  return on;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

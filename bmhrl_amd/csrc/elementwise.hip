@@ -350,6 +350,31 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ tok, const int64_t*
   }
 }
 
+// BMHRL_DETERMINISTIC: a thread owns a column and walks the rows in order (rows that repeat a token add in row order)
+__global__ void embed_bwd_ordered_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ tok2, float mix,
+                                         const float* __restrict__ dC, float* __restrict__ dtable, int D, long rows, float scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  for (long row = 0; row < rows; ++row) {
+    const float g = dC[row * D + c] * scale;
+    if (tok2) {
+      dtable[tok[row] * D + c] += g * (1.f - mix);
+      dtable[tok2[row] * D + c] += g * mix;
+    } else {
+      dtable[tok[row] * D + c] += g;
+    }
+  }
+}
+__global__ void scatter_add_rows_ordered_kernel(const float* __restrict__ dout, const int32_t* __restrict__ src, float* __restrict__ dx,
+                                                int D, long rows) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  for (long r = 0; r < rows; ++r) {
+    const int s = src[r];
+    if (s >= 0) dx[(long)s * D + c] += dout[r * D + c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ casts / sums
 __global__ void cast_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows,
                                  int cols, float scale, float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
@@ -965,17 +990,24 @@ extern "C" int bmhrl_layernorm_fwd(const float* x, const float* gamma, const flo
   return hip_status(hipGetLastError());
 }
 
-extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
-                                   int64_t rows, int32_t D, bmhrl_stream_t stream) {
-  BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 64 * LN_MAXC);
+extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                                      int64_t rows, int32_t D, float* workspace, int64_t workspace_floats,
+                                      bmhrl_stream_t stream);
+extern "C" int64_t bmhrl_layernorm_bwd_workspace(int64_t rows, int32_t D);
+
+// the one-launch form: parameter gradients by one atomic per column and block
+static int ln_bwd_direct(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                         const float* dx_add, float* dgamma, float* dbeta, int64_t rows, int32_t D, bmhrl_stream_t stream) {
   // ~512 blocks (2048 waves): fills the chip and keeps the dgamma/dbeta atomics at ~512 per column
   int rpw = (int)((rows + 2047) / 2048);
   if (rpw < 1) rpw = 1;
   if (rpw > 32) rpw = 32;
+  if (bmhrl_deterministic()) rpw = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);    // (rows no vector form serves: one block)
   const long waves = (rows + rpw - 1) / rpw;
   dim3 grid((unsigned)((waves + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-  if (D % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0)) {
+  if (!bmhrl_deterministic() && D % 4 == 0 &&
+      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0)) {
     // ~1024 waves (256 blocks): measured optimum on MI355X between streaming parallelism and the dgamma/dbeta atomics
     // (one per column per block, all blocks onto the same D addresses: 1024 blocks cost 2x the time of 256)
     static const int target = getenv("BMHRL_LN_WAVES") ? atoi(getenv("BMHRL_LN_WAVES")) : 1024;
@@ -997,6 +1029,15 @@ extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float*
   if (nc <= 1) LN_BWD(1); else if (nc <= 2) LN_BWD(2); else if (nc <= 5) LN_BWD(5); else if (nc <= 8) LN_BWD(8); else LN_BWD(16);
 #undef LN_BWD
   return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, float* dx, const float* dx_add, float* dgamma, float* dbeta,
+                                   int64_t rows, int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 64 * LN_MAXC);
+  // (BMHRL_DETERMINISTIC: without a workspace the ordered form is ONE block -- correct, slow on long inputs; callers that
+  //  care pass a workspace: bmhrl_layernorm_bwd_ws, as bmhrl_amd.ops.layernorm_bwd does)
+  return ln_bwd_direct(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D, stream);
 }
 
 // Two-stage variant: ~4 waves per SIMD stream the rows, column sums go through `workspace`.
@@ -1029,7 +1070,7 @@ extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const flo
   const bool vec = D % 4 == 0 && D <= 1024 &&
                    ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0);
   if (!vec || !workspace || (!dgamma && !dbeta) || workspace_floats < bmhrl_layernorm_bwd_workspace(rows, D))
-    return bmhrl_layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D, stream);
+    return ln_bwd_direct(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows, D, stream);
   int rv; long blocks;
   ln_bwd_ws_plan(rows, D, &rv, &blocks);
   dim3 gridv((unsigned)blocks), block(256);
@@ -1040,7 +1081,7 @@ extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const flo
   // few blocks (the caption-side rows: 480 x 300 -> 120 blocks): the same-address atomics are short then, and cheaper
   // than a second launch on the step's serial chain
   static const long atomic_max = getenv("BMHRL_LN_ATOMIC_BLOCKS") ? atol(getenv("BMHRL_LN_ATOMIC_BLOCKS")) : 128;
-  if (blocks <= atomic_max) {
+  if (blocks <= atomic_max && !bmhrl_deterministic()) {
 #define LN_BWDA(NV_) hipLaunchKernelGGL((ln_bwd_vec_kernel<NV_, false>), gridv, block, 0, S_(stream), dy, x, gamma, mean, rstd, dx, \
                                         dx_add, dgamma, dbeta, (long)rows, D, rv, (float*)nullptr)
     if (nv <= 1) LN_BWDA(1); else if (nv <= 2) LN_BWDA(2); else LN_BWDA(4);
@@ -1055,7 +1096,7 @@ extern "C" int bmhrl_layernorm_bwd_ws(const float* dy, const float* x, const flo
   int rg = (int)((256 + cg - 1) / cg);                         // ~256 blocks in total
   const int max_rg = (int)((blocks + 3) / 4);
   if (rg > max_rg) rg = max_rg;
-  if (rg < 1) rg = 1;
+  if (rg < 1 || bmhrl_deterministic()) rg = 1;           // (deterministic: one block sums a column's partials, in order)
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cg, rg), block, 0, S_(stream), workspace, (int)blocks, D, dgamma, dbeta);
   return hip_status(hipGetLastError());
 }
@@ -1098,7 +1139,7 @@ extern "C" int bmhrl_layernorm_bwd_groups(const float* dy, const float* x, const
   static const long atomic_max = getenv("BMHRL_LN_ATOMIC_BLOCKS") ? atol(getenv("BMHRL_LN_ATOMIC_BLOCKS")) : 128;
   const bool vec = D % 4 == 0 && D <= 1024 &&
                    ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0);
-  if (!vec || groups == 1 || blocks > atomic_max) {
+  if (!vec || groups == 1 || blocks > atomic_max || bmhrl_deterministic()) {
     for (int g = 0; g < groups; ++g) {
       const int rc = bmhrl_layernorm_bwd(dy + g * rows * D, x + g * rows * D, gamma + (long)g * D, mean + g * rows, rstd + g * rows,
                                          dx + g * rows * D, dx_add ? dx_add + g * rows * D : nullptr,
@@ -1140,8 +1181,12 @@ extern "C" int bmhrl_embed_bwd(const int64_t* tok, const int64_t* tok2, float mi
                                int32_t B, int32_t L, int32_t D, float scale, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(tok && dC && dtable && B > 0 && L > 0 && D > 0);
   const long total = (long)B * L * D;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), tok, tok2, mix, dC, dtable, D,
-                     total, scale);
+  if (bmhrl_deterministic())
+    hipLaunchKernelGGL(embed_bwd_ordered_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, S_(stream), tok, tok2, mix, dC, dtable,
+                       D, (long)B * L, scale);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), tok, tok2, mix, dC, dtable, D,
+                       total, scale);
   return hip_status(hipGetLastError());
 }
 
@@ -1191,6 +1236,7 @@ extern "C" int bmhrl_cast_colsum_bf16_groups(const float* x, int64_t ldx, void* 
   // same address serialise (a 128-wide matrix cut into 512 row blocks spent 13 of its 16 us there)
   int row_blocks = 512 / col_blocks;
   row_blocks = row_blocks < 1 ? 1 : (row_blocks > 128 ? 128 : row_blocks);
+  if (bmhrl_deterministic()) row_blocks = 1;             // one block per column block and group: one add per address
   int rpb = (int)((rows + row_blocks - 1) / row_blocks);
   if (rpb < 16) rpb = 16;
   const int bpg = (int)((rows + rpb - 1) / rpb);
@@ -1219,6 +1265,7 @@ extern "C" int bmhrl_colsum_bf16(const void* dY, int64_t ld, float* db, int32_t 
   const int col_blocks = (cols + 511) / 512;
   int rpb = (int)((rows * col_blocks + 511) / 512);      // aim at ~512 blocks in total
   if (rpb < 16) rpb = 16;
+  if (bmhrl_deterministic()) rpb = (int)rows;            // one block per column block: one add per address
   dim3 grid((unsigned)col_blocks, (unsigned)((rows + rpb - 1) / rpb)), block(256);
   hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows, cols, rpb, 0l);
   return hip_status(hipGetLastError());
@@ -1232,6 +1279,7 @@ extern "C" int bmhrl_colsum_bf16_groups(const void* dY, int64_t ld, float* db, i
   const int col_blocks = (cols + 511) / 512;
   int rpb = (int)((rows_per_group * groups * col_blocks + 511) / 512);
   if (rpb < 16) rpb = 16;
+  if (bmhrl_deterministic()) rpb = (int)rows_per_group;
   dim3 grid((unsigned)col_blocks, (unsigned)((rows_per_group + rpb - 1) / rpb), (unsigned)groups), block(256);
   hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, S_(stream), (const bf16_t*)dY, (long)ld, db, (long)rows_per_group, cols, rpb,
                      (long)db_stride);
@@ -1293,8 +1341,8 @@ extern "C" int bmhrl_gate_bwd(const float* dout, const float* cv, const float* c
                               float* da_v, int64_t rows, int32_t D, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(dout && cv && ca && a_v && dcv && dca && rows > 0 && D > 0);
   const long total = rows * D;
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(total, 256, 256)), dim3(256), 0, S_(stream), dout, cv, ca, a_v, dcv, dca,
-                     da_v, total);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(bmhrl_deterministic() ? 1u : grid_for(total, 256, 256)), dim3(256), 0, S_(stream), dout,
+                     cv, ca, a_v, dcv, dca, da_v, total);       // (deterministic: one block = one add into da_v)
   return hip_status(hipGetLastError());
 }
 
@@ -1317,7 +1365,11 @@ extern "C" int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, flo
                                       bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(dout && src && dx && rows > 0 && D > 0);
   const long total = rows * D;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), dout, src, dx, D, total);
+  if (bmhrl_deterministic())
+    hipLaunchKernelGGL(scatter_add_rows_ordered_kernel, dim3((unsigned)((D + 63) / 64)), dim3(64), 0, S_(stream), dout, src, dx, D,
+                       (long)rows);
+  else
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), dout, src, dx, D, total);
   return hip_status(hipGetLastError());
 }
 

@@ -898,10 +898,30 @@ TilePlan tile_plan(int M, int N, int K, int batch, bool can_split) {
   // the captured step, where the audio branch runs next to these GEMMs, the step measured 6.06 - 6.23 ms with them against
   // 5.95 ms without, so the option is off by default (BMHRL_GEMM_MIDMAX=256 turns it on, BMHRL_GEMM_TILE=3 forces it).
   static const int mid_max = getenv("BMHRL_GEMM_MIDMAX") ? atoi(getenv("BMHRL_GEMM_MIDMAX")) : 0;
+  if (bmhrl_deterministic()) splits = 1;          // (atomics of a K split land in scheduling order)
   t.mid = force_tile ? force_tile == 3 : (big && splits == 1 && big_tiles <= mid_max);
   t.big = big;
   t.splits = splits;
   return t;
+}
+
+// BMHRL_DETERMINISTIC: the column sums the epilogue would add with one atomic per tile -- one thread per column walks the
+// batches and rows of the OUTPUT in order instead (sums of the stored, rounded values).
+__global__ void colsum_ordered_kernel(const GemmArgs p, int batch1) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= p.N) return;
+  for (int b1 = 0; b1 < batch1; ++b1)
+    for (int b2 = 0; b2 < p.batch2; ++b2) {
+      float acc = 0.f;
+      if (p.Cb) {
+        const bf16_t* c = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 + n;
+        for (int m = 0; m < p.M; ++m) acc += (float)c[(long)m * p.ldcb];
+      } else {
+        const float* c = p.C + b1 * p.c_sb1 + b2 * p.c_sb2 + n;
+        for (int m = 0; m < p.M; ++m) acc += c[(long)m * p.ldc];
+      }
+      p.colsum[b1 * p.cs_sb1 + b2 * p.cs_sb2 + n] += acc;
+    }
 }
 
 }  // namespace
@@ -971,10 +991,17 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   TilePlan tp;
   int batch;
   if (const int rc = prepare(d, a, tp, batch)) return rc;
+  const bool ordered_colsum = bmhrl_deterministic() && a.colsum != nullptr;
+  GemmArgs full = a;
+  if (ordered_colsum) a.colsum = nullptr;
   hipError_t e;
   if (tp.mid) e = launch<2, 1>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
   else if (tp.big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
   else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
+  if (e == hipSuccess && ordered_colsum) {
+    hipLaunchKernelGGL(colsum_ordered_kernel, dim3((unsigned)((full.N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, full, d->batch1);
+    e = hipGetLastError();
+  }
   return hip_status(e);
 }
 

@@ -449,6 +449,16 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     if stats[0] == "mat" and _use_small(dk, Sq, Sk, ldq, ldk, ldv, lddq, lddk, lddv, q_off, k_off, v_off, dq_off, dk_off, dv_off):
         t = lambda d: (None, 0) if d is None else d
         (bq, oq), (bk, ok), (bv, ov) = t(db_q), t(db_k), t(db_v)
+        if ops.DETERMINISTIC and (bq is not None or bk is not None or bv is not None):
+            # the kernel's bias sums are one atomic per (sample, head) block and column: ordered column sums afterwards instead
+            ops.small_attention_bwd(dOb, H * dk, stats[1], pad8(Sk), Qb, Kb, Vb, dQb, dKb, dVb, mask, msb, msq, B, H, Sq, Sk, dk,
+                                    1.0 / math.sqrt(dk), ldq, ldk, ldv, lddq, lddk, lddv, q_off=q_off, k_off=k_off, v_off=v_off,
+                                    dq_off=dq_off, dk_off=dk_off, dv_off=dv_off)
+            for db, off, buf, ld, boff, rows in ((bq, oq, dQb, lddq, dq_off, B * Sq), (bk, ok, dKb, lddk, dk_off, B * Sk),
+                                                  (bv, ov, dVb, lddv, dv_off, B * Sk)):
+                if db is not None:
+                    ops.colsum_bf16(buf, ld, db, True, rows, H * dk, dy_off=boff, db_off=off)
+            return
         ops.small_attention_bwd(dOb, H * dk, stats[1], pad8(Sk), Qb, Kb, Vb, dQb, dKb, dVb, mask, msb, msq, B, H, Sq, Sk, dk,
                                 1.0 / math.sqrt(dk), ldq, ldk, ldv, lddq, lddk, lddv, q_off=q_off, k_off=k_off, v_off=v_off,
                                 dq_off=dq_off, dk_off=dk_off, dv_off=dv_off, dbq=bq, dbk=bk, dbv=bv, dbq_off=oq, dbk_off=ok,

@@ -170,7 +170,9 @@ class BMFusionLayer(nn.Module):
     branch_side_stream = True
     _side = None
     absorb_memory_projections = True
-    fused_tail = os.environ.get("BMHRL_FUSED_TAIL", "1") == "1"     # normCA, normCV and the gate as one launch (functional.FusionTailFn)
+    # normCA, normCV and the gate as one launch (functional.FusionTailFn); its parameter gradients are per-block atomics, so
+    # BMHRL_DETERMINISTIC takes the separate LayerNorm / gate kernels (ordered sums)
+    fused_tail = os.environ.get("BMHRL_FUSED_TAIL", "1") == "1" and os.environ.get("BMHRL_DETERMINISTIC", "0") in ("", "0")
 
     def _tail_params(self):
         return (self.normCA.weight, self.normCA.bias, self.normCV.weight, self.normCV.bias, self.a_v_constant)

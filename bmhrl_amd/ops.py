@@ -236,9 +236,19 @@ def layernorm_fwd_groups(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows_pe
                "bmhrl_layernorm_fwd_groups")
 
 
+DETERMINISTIC = os.environ.get("BMHRL_DETERMINISTIC", "0") not in ("", "0")   # (the library reads the same variable)
+
+
 def layernorm_bwd_groups(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows_per_group, D, groups):
     """backward of layernorm_fwd_groups; dgamma / dbeta (groups, D) are ADDED to (zero them first)"""
     _need_cuda(x)
+    if DETERMINISTIC:           # ordered parameter gradients: the two-stage form with a workspace per call, group by group
+        R = rows_per_group
+        for g in range(groups):
+            sl = lambda t, n: None if t is None else t.reshape(-1)[g * n:(g + 1) * n]
+            layernorm_bwd(sl(dy, R * D), sl(x, R * D), sl(gamma, D), sl(mean, R), sl(rstd, R), sl(dx, R * D), sl(dx_add, R * D),
+                          sl(dgamma, D), sl(dbeta, D), R, D)
+        return
     if gamma.numel() != groups * D or any(t is not None and t.numel() != groups * D for t in (dgamma, dbeta)):
         raise RuntimeError("layernorm_bwd_groups: gamma / dgamma / dbeta must hold one row of D per group")
     _lib.check(_lib.load().bmhrl_layernorm_bwd_groups(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),

@@ -48,3 +48,42 @@ def test_split_backward_equals_single_phase():
         moved0 = float((p0[lo:hi] - init[lo:hi]).norm())
         moved1 = float((p1[lo:hi] - init[lo:hi]).norm())
         assert moved0 > 0 and abs(moved1 - moved0) <= 5e-2 * moved0, (lo, hi, moved0, moved1)
+
+
+_DET_SCRIPT = r"""
+import sys, torch
+from bmhrl_amd import synthetic as syn
+from bmhrl_amd.train import CaptionTrainer
+dev = torch.device("cuda:0")
+b = syn.synthetic_batch(2, 128, 200, 12, 300, seed=2)
+fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
+cap = b["captions"].to(dev)
+t = CaptionTrainer(syn.default_cfg(dout_p=0.1), 300, dev, lr=1e-3)
+t.agent.train()
+t.split_backward = sys.argv[2] == "split"
+t.capture(fs, cap, warmup=1)
+losses = [float(t.replay()) for _ in range(3)]
+torch.save({"losses": losses, "flat": t.opt.flat.cpu()}, sys.argv[1])
+"""
+
+
+def test_deterministic_mode_runs_agree_bit_for_bit(tmp_path):
+    """BMHRL_DETERMINISTIC=1 (no K split, ordered column sums / LayerNorm parameter gradients / embedding and scatter
+    gradients): two separately started runs of the same captured step -- dropout on -- end with IDENTICAL losses and weights,
+    and the phased backward equals the single-phase one exactly (the default mode only agrees up to the order of its atomics)."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMHRL_DETERMINISTIC="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    outs = []
+    for i, mode in enumerate(("single", "single", "split")):
+        f = tmp_path / f"run{i}.pt"
+        r = subprocess.run([sys.executable, "-c", _DET_SCRIPT, str(f), mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    assert outs[0]["losses"] == outs[1]["losses"] and torch.equal(outs[0]["flat"], outs[1]["flat"])
+    assert outs[0]["losses"] == outs[2]["losses"] and torch.equal(outs[0]["flat"], outs[2]["flat"])
+    assert all(x == x for x in outs[0]["losses"]) and outs[0]["losses"][2] < outs[0]["losses"][0]
