@@ -907,20 +907,38 @@ TilePlan tile_plan(int M, int N, int K, int batch, bool can_split) {
 
 // BMHRL_DETERMINISTIC: the column sums the epilogue would add with one atomic per tile -- one thread per column walks the
 // batches and rows of the OUTPUT in order instead (sums of the stored, rounded values).
-__global__ void colsum_ordered_kernel(const GemmArgs p, int batch1) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= p.N) return;
+__global__ __launch_bounds__(1024) void colsum_ordered_kernel(const GemmArgs p, int batch1) {
+  // block = 64 columns x 16 row lanes; a thread takes every 16th row, eight loads in flight; the partial sums meet in a fixed order
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   for (int b1 = 0; b1 < batch1; ++b1)
     for (int b2 = 0; b2 < p.batch2; ++b2) {
-      float acc = 0.f;
-      if (p.Cb) {
-        const bf16_t* c = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 + n;
-        for (int m = 0; m < p.M; ++m) acc += (float)c[(long)m * p.ldcb];
-      } else {
-        const float* c = p.C + b1 * p.c_sb1 + b2 * p.c_sb2 + n;
-        for (int m = 0; m < p.M; ++m) acc += c[(long)m * p.ldc];
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) {
+        if (p.Cb) {
+          const bf16_t* c = p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 + n;
+          for (int m = rl; m < p.M; m += 128)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (m + 16 * j < p.M) a[j] += (float)c[(long)(m + 16 * j) * p.ldcb];
+        } else {
+          const float* c = p.C + b1 * p.c_sb1 + b2 * p.c_sb2 + n;
+          for (int m = rl; m < p.M; m += 128)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (m + 16 * j < p.M) a[j] += c[(long)(m + 16 * j) * p.ldc];
+        }
       }
-      p.colsum[b1 * p.cs_sb1 + b2 * p.cs_sb2 + n] += acc;
+      __syncthreads();
+      red[rl][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      __syncthreads();
+      if (rl == 0 && n < p.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        p.colsum[b1 * p.cs_sb1 + b2 * p.cs_sb2 + n] += t;
+      }
     }
 }
 
@@ -999,7 +1017,7 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   else if (tp.big) e = launch<2, 2>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
   else e = launch<1, 1>(a, d->a_trans, d->b_trans, batch, tp.splits, (hipStream_t)stream);
   if (e == hipSuccess && ordered_colsum) {
-    hipLaunchKernelGGL(colsum_ordered_kernel, dim3((unsigned)((full.N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, full, d->batch1);
+    hipLaunchKernelGGL(colsum_ordered_kernel, dim3((unsigned)((full.N + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, full, d->batch1);
     e = hipGetLastError();
   }
   return hip_status(e);
