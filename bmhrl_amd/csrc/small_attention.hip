@@ -4,15 +4,16 @@
 // row term + dS GEMM + three gradient GEMMs backward: eight dependent launches of a few microseconds of work each on the
 // step's serial chain.  Here a workgroup (4 waves) owns one (batch row, head):
 //
-//   forward : Q, K row-major and V transposed go to LDS; every wave forms S^T = K Q^T (32 x 32 x d_k, the key rows fed in a
+//   forward : Q, K, V go to LDS row-major (V^T fragments come out of ds_read_b64_tr_b16); every wave forms S^T = K Q^T (32 x 32 x d_k, the key rows fed in a
 //             permuted order so that the accumulator layout of S^T IS the B-operand layout of the next product), softmax over
 //             the 16 registers + one cross-half exchange, P (bf16, the tensor the backward needs) stored by wave 0, then the
 //             waves split the d_k columns of O^T = V^T P^T, apply the output dropout (same element ids as the GEMM epilogue
 //             it replaces) and the rows leave through an LDS image as whole 16-byte pieces.
 //   backward: dP^T = V dO^T in the same layout as P^T; delta = sum_k P dP from the SAME rounded P (attention.hip:
 //             softmax_bwd_rows_kernel), dS^T = scale P (dP - delta), zero at masked keys (masked_fill passes no gradient);
-//             dQ^T = K^T dS^T takes dS^T straight from the registers, dV^T = dO^T P and dK^T = Q^T dS go through small
-//             transposed LDS copies; optional bias gradients (column sums of dQ / dK / dV) by one atomic per column.
+//             dQ^T = K^T dS^T takes dS^T straight from the registers, dV^T = dO^T P and dK^T = Q^T dS take P^T / dS^T from small
+//             LDS copies; the transposed operands (dO^T, K^T, Q^T) are transposed reads of the row-major images; optional
+//             bias gradients (column sums of dQ / dK / dV) by one atomic per column.
 //
 // Roofline: none worth the name -- 128 workgroups of ~2 MFLOP; the launch is bound by its dependent load -> LDS -> MFMA chain
 // (~5 us), which is the point: it replaces ~45 us of launches.
@@ -21,8 +22,9 @@
 
 namespace {
 
-constexpr int SA_PAD = 8;        // row padding (elements) of the row-major LDS images: rows stay 16-byte aligned
-constexpr int SA_TROW = 40;      // row length (elements) of the transposed images: 32 keys / queries + padding
+constexpr int SA_PAD = 8;        // row padding (elements) of the images read along their rows (ds_read_b128: conflict free)
+constexpr int SA_TPAD = 32;      // ... of the images read transposed (the 4 rows of a ds_read_b64_tr_b16 block on 4 bank quarters)
+constexpr int SA_TROW = 40;      // row length (elements) of the P^T / dS^T images: 32 queries + padding
 
 struct SmallAttnArgs {
   const bf16_t* Q; long ldq;
@@ -49,27 +51,23 @@ __device__ __forceinline__ int key_of_row(int rho) {
 
 // rows [0, nrows) x DK columns of a row-major bf16 matrix (row stride ld) -> LDS image with row stride DK + SA_PAD; rows
 // >= nrows (up to 32) are zero
-template <int DK>
+template <int DK, int PAD>
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ g, long ld, int nrows, bf16_t* s) {
   constexpr int CPR = DK / 8;
   for (int c = threadIdx.x; c < 32 * CPR; c += 256) {
     const int row = c / CPR, ch = c % CPR;
     bf16x8 v = zero_bf16x8();
     if (row < nrows) v = *reinterpret_cast<const bf16x8*>(g + (long)row * ld + ch * 8);
-    *reinterpret_cast<bf16x8*>(s + row * (DK + SA_PAD) + ch * 8) = v;
+    *reinterpret_cast<bf16x8*>(s + row * (DK + PAD) + ch * 8) = v;
   }
 }
-// the same matrix transposed: image[d][row], row stride SA_TROW
-template <int DK>
-__device__ __forceinline__ void stage_transposed(const bf16_t* __restrict__ g, long ld, int nrows, bf16_t* s) {
-  constexpr int CPR = DK / 8;
-  for (int c = threadIdx.x; c < 32 * CPR; c += 256) {
-    const int row = c % 32, ch = c / 32;           // consecutive threads: consecutive rows (LDS writes of a wave spread over banks)
-    bf16x8 v = zero_bf16x8();
-    if (row < nrows) v = *reinterpret_cast<const bf16x8*>(g + (long)row * ld + ch * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[(ch * 8 + j) * SA_TROW + row] = v[j];
-  }
+// A-operand fragment of X^T (rows d0 + (lane & 31), eight consecutive rows of X from row k0 + 8 (lane >> 5)) out of the
+// row-major image X[row][d] with row stride LD: two transposed reads (gemm.hip's pattern)
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_transposed(const bf16_t* img, int k0, int d0, int lane) {
+  const int hh = lane >> 5, g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const bf16_t* base = img + (k0 + 8 * hh + q4) * LD + d0 + 16 * g1 + 4 * p4;
+  return join8(lds_read_tr4(base), lds_read_tr4(base + 4 * LD));
 }
 // LDS image [row][DK + SA_PAD] -> rows [0, nrows) of a row-major global matrix, 16 bytes per thread and step
 template <int DK>
@@ -98,16 +96,17 @@ __device__ __forceinline__ void tile_to_image(const f32x16& acc, bf16_t* img, in
 template <int DK>
 __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const SmallAttnArgs p) {
   constexpr int LDR = DK + SA_PAD;
+  constexpr int LDT = DK + SA_TPAD;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LDR];      // Q rows; later the output image
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[DK * SA_TROW];  // V^T: [d][key]
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * LDT];      // V rows, read transposed
   const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const long D = (long)p.H * DK;
-  stage_rows<DK>(p.Q + (long)b * p.Sq * p.ldq + hd * DK, p.ldq, p.Sq, Qs);
-  stage_rows<DK>(p.K + (long)b * p.Sk * p.ldk + hd * DK, p.ldk, p.Sk, Ks);
-  stage_transposed<DK>(p.V + (long)b * p.Sk * p.ldv + hd * DK, p.ldv, p.Sk, Vt);
+  stage_rows<DK, SA_PAD>(p.Q + (long)b * p.Sq * p.ldq + hd * DK, p.ldq, p.Sq, Qs);
+  stage_rows<DK, SA_PAD>(p.K + (long)b * p.Sk * p.ldk + hd * DK, p.ldk, p.Sk, Ks);
+  stage_rows<DK, SA_TPAD>(p.V + (long)b * p.Sk * p.ldv + hd * DK, p.ldv, p.Sk, Vs);
   __syncthreads();
 
   // S^T[key][q]: A rows = keys in the permuted order, B rows = queries
@@ -157,9 +156,8 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const SmallAttnArgs
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const bf16_t* va = Vt + (dt * 32 + r32) * SA_TROW + 8 * hh;
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(va), pf[0], o, 0, 0, 0);
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(va + 16), pf[1], o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(Vs, 0, dt * 32, lane), pf[0], o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(Vs, 16, dt * 32, lane), pf[1], o, 0, 0, 0);
     if (p.dropout_p > 0.f) {
       const uint64_t base = ((uint64_t)b * p.Sq + q) * (uint64_t)D + (uint64_t)hd * DK + dt * 32 + 4 * hh;
 #pragma unroll
@@ -173,24 +171,21 @@ __global__ __launch_bounds__(256) void small_attn_fwd_kernel(const SmallAttnArgs
 
 template <int DK>
 __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const SmallAttnArgs p) {
-  constexpr int LDR = DK + SA_PAD;
-  // R1: V and dO row-major (phase A), then K^T (dQ), then Q^T (dK).  dOt: dO^T.  Out: output image of a gradient.
-  __shared__ __attribute__((aligned(16))) bf16_t R1[2 * 32 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t dOt[DK * SA_TROW];
-  __shared__ __attribute__((aligned(16))) bf16_t Out[32 * LDR];
+  constexpr int LDR = DK + SA_PAD, LDT = DK + SA_TPAD;
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * LDR];       // V rows (phase A); then the output image of a gradient
+  __shared__ __attribute__((aligned(16))) bf16_t dOs[32 * LDT];      // dO rows: along the rows for dP^T, transposed for dV^T
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LDT];       // K rows, read transposed (dQ^T = K^T dS^T)
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LDT];       // Q rows, read transposed (dK^T = Q^T dS)
   __shared__ __attribute__((aligned(16))) bf16_t Pt[32 * SA_TROW];   // P^T [key][q]
   __shared__ __attribute__((aligned(16))) bf16_t dSt[32 * SA_TROW];  // dS^T [key][q]
-  static_assert(DK * SA_TROW <= 2 * 32 * LDR, "the transposed image of K / Q fits the region of the two row-major ones");
-  bf16_t* const Vs = R1;
-  bf16_t* const dOs = R1 + 32 * LDR;
-  bf16_t* const Tt = R1;                            // K^T, then Q^T
+  bf16_t* const Out = Vs;
   const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
-  const bf16_t* dOg = p.dO + (long)b * p.Sq * p.lddo + hd * DK;
-  stage_rows<DK>(p.V + (long)b * p.Sk * p.ldv + hd * DK, p.ldv, p.Sk, Vs);
-  stage_rows<DK>(dOg, p.lddo, p.Sq, dOs);
-  stage_transposed<DK>(dOg, p.lddo, p.Sq, dOt);
+  stage_rows<DK, SA_PAD>(p.V + (long)b * p.Sk * p.ldv + hd * DK, p.ldv, p.Sk, Vs);
+  stage_rows<DK, SA_TPAD>(p.dO + (long)b * p.Sq * p.lddo + hd * DK, p.lddo, p.Sq, dOs);
+  stage_rows<DK, SA_TPAD>(p.K + (long)b * p.Sk * p.ldk + hd * DK, p.ldk, p.Sk, Ks);
+  stage_rows<DK, SA_TPAD>(p.Q + (long)b * p.Sq * p.ldq + hd * DK, p.ldq, p.Sq, Qs);
   __syncthreads();
 
   // dP^T[key][q] = V dO^T, keys in the permuted order of the forward: same layout as P^T below
@@ -199,7 +194,7 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const SmallAttnArgs
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   {
     const bf16_t* va = Vs + key_of_row(r32) * LDR + 8 * hh;
-    const bf16_t* gb = dOs + r32 * LDR + 8 * hh;
+    const bf16_t* gb = dOs + r32 * LDT + 8 * hh;
 #pragma unroll 4
     for (int ks = 0; ks < DK / 16; ++ks)
       acc = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(va + 16 * ks), *reinterpret_cast<const bf16x8*>(gb + 16 * ks), acc, 0, 0, 0);
@@ -232,37 +227,33 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const SmallAttnArgs
       dSt[key * SA_TROW + q] = sf[r >> 3][r & 7];
     }
   }
-  __syncthreads();                                  // Pt / dSt visible; Vs, dOs dead
+  __syncthreads();                                  // Pt / dSt visible; every wave is done with Vs: it becomes the output image
 
   // ---- dV^T = dO^T P  (rows d, columns key)
-  stage_transposed<DK>(p.K + (long)b * p.Sk * p.ldk + hd * DK, p.ldk, p.Sk, Tt);      // K^T for the next phase, under these MFMAs
   for (int dt = wave; dt < DK / 32; dt += 4) {
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const bf16_t* a = dOt + (dt * 32 + r32) * SA_TROW + 8 * hh;
     const bf16_t* bb = Pt + r32 * SA_TROW + 8 * hh;
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(a), *reinterpret_cast<const bf16x8*>(bb), o, 0, 0, 0);
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(a + 16), *reinterpret_cast<const bf16x8*>(bb + 16), o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(dOs, 0, dt * 32, lane), *reinterpret_cast<const bf16x8*>(bb), o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(dOs, 16, dt * 32, lane), *reinterpret_cast<const bf16x8*>(bb + 16), o, 0, 0, 0);
     tile_to_image(o, Out, LDR, dt * 32, r32, hh);
   }
   __syncthreads();
   store_rows<DK>(Out, p.dV + (long)b * p.Sk * p.lddv + hd * DK, p.lddv, p.Sk);
   if (p.dbv) colsum_rows<DK>(Out, p.Sk, p.dbv + hd * DK);
-  __syncthreads();                                  // Out free again; K^T staged
+  __syncthreads();
 
   // ---- dQ^T = K^T dS^T  (rows d, columns q), dS^T from the registers
   for (int dt = wave; dt < DK / 32; dt += 4) {
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const bf16_t* a = Tt + (dt * 32 + r32) * SA_TROW + 8 * hh;
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(a), sf[0], o, 0, 0, 0);
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(a + 16), sf[1], o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(Ks, 0, dt * 32, lane), sf[0], o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(Ks, 16, dt * 32, lane), sf[1], o, 0, 0, 0);
     tile_to_image(o, Out, LDR, dt * 32, r32, hh);
   }
-  __syncthreads();                                  // K^T dead
-  stage_transposed<DK>(p.Q + (long)b * p.Sq * p.ldq + hd * DK, p.ldq, p.Sq, Tt);      // Q^T
+  __syncthreads();
   store_rows<DK>(Out, p.dQ + (long)b * p.Sq * p.lddq + hd * DK, p.lddq, p.Sq);
   if (p.dbq) colsum_rows<DK>(Out, p.Sq, p.dbq + hd * DK);
   __syncthreads();
@@ -272,10 +263,9 @@ __global__ __launch_bounds__(256) void small_attn_bwd_kernel(const SmallAttnArgs
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const bf16_t* a = Tt + (dt * 32 + r32) * SA_TROW + 8 * hh;
     const bf16_t* bb = dSt + r32 * SA_TROW + 8 * hh;
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(a), *reinterpret_cast<const bf16x8*>(bb), o, 0, 0, 0);
-    o = BMHRL_MFMA16(*reinterpret_cast<const bf16x8*>(a + 16), *reinterpret_cast<const bf16x8*>(bb + 16), o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(Qs, 0, dt * 32, lane), *reinterpret_cast<const bf16x8*>(bb), o, 0, 0, 0);
+    o = BMHRL_MFMA16(frag_transposed<LDT>(Qs, 16, dt * 32, lane), *reinterpret_cast<const bf16x8*>(bb + 16), o, 0, 0, 0);
     tile_to_image(o, Out, LDR, dt * 32, r32, hh);
   }
   __syncthreads();
