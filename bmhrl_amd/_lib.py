@@ -79,7 +79,7 @@ PROTOTYPES = {
     "bmhrl_embed_posenc": [ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, i32, i32, f32, f32, u64, ptr, ptr],
     "bmhrl_embed_bwd": [ptr, ptr, f32, ptr, ptr, i32, i32, i32, f32, ptr],
     "bmhrl_cast_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr],
-    "bmhrl_cast_split3_bf16": [ptr, i64, ptr, i64, i64, i32, i64, i32, ptr],
+    "bmhrl_cast_split3_bf16": [ptr, i64, ptr, i64, i64, i32, i64, i32, ptr, i64, i32, ptr],
     "bmhrl_cast_colsum_bf16": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, ptr],
     "bmhrl_cast_colsum_bf16_groups": [ptr, i64, ptr, i64, i64, i32, f32, f32, u64, ptr, ptr, i64, i64, ptr],
     "bmhrl_cast_segments": [ptr, i32, i32, ptr],

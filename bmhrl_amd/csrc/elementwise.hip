@@ -407,12 +407,14 @@ __global__ void cast_bf16_copies_kernel(const float* __restrict__ x, long ldx, b
 // [hi | lo | hi] gives x_hi W_hi + x_hi W_lo + x_lo W_hi in ONE GEMM with K = 3 part: the product to ~16 mantissa bits (the
 // lo x lo term, 2^-18 relative, is dropped).  Used for the vocabulary projection, whose logits carry north_star's 1e-3 bound.
 __global__ void cast_split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long part, int lo_slot,
-                                   long rows, int cols) {
-  const long total = rows * cols;
+                                   long rows, int cols, const float* __restrict__ x2, long ldx2, int cols2) {
+  // (x2: a second source whose cols2 columns follow x's -- the operand cat[x, goal completion] of the vocabulary head)
+  const int ct = cols + cols2;
+  const long total = rows * ct;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = i % cols;
-    const long r = i / cols;
-    const float v = x[r * ldx + c];
+    const int c = i % ct;
+    const long r = i / ct;
+    const float v = c < cols ? x[r * ldx + c] : x2[r * ldx2 + c - cols];
     const bf16_t hi = (bf16_t)v;
     bf16_t* o = y + r * ldy + c;
     o[0] = hi;
@@ -1211,10 +1213,13 @@ extern "C" int bmhrl_cast_colsum_bf16_groups(const float* x, int64_t ldx, void* 
                                              float* colsum, int64_t group_rows, int64_t colsum_stride, bmhrl_stream_t stream);
 
 extern "C" int bmhrl_cast_split3_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part, int32_t lo_slot,
-                                      int64_t rows, int32_t cols, bmhrl_stream_t stream) {
-  BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && part >= cols && ldy >= 3 * part && (lo_slot == 1 || lo_slot == 2));
-  hipLaunchKernelGGL(cast_split3_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y, (long)ldy,
-                     (long)part, lo_slot, (long)rows, cols);
+                                      int64_t rows, int32_t cols, const float* x2, int64_t ldx2, int32_t cols2,
+                                      bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= 3 * part && (lo_slot == 1 || lo_slot == 2));
+  if (!x2) cols2 = 0;
+  BMHRL_CHECK_ARG(cols2 >= 0 && part >= cols + cols2 && (!x2 || ldx2 >= cols2));
+  hipLaunchKernelGGL(cast_split3_kernel, dim3(grid_for(rows * (cols + cols2))), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)y,
+                     (long)ldy, (long)part, lo_slot, (long)rows, cols, x2, (long)ldx2, cols2);
   return hip_status(hipGetLastError());
 }
 

@@ -556,14 +556,14 @@ class MHAFn(torch.autograd.Function):
         self_att = kv_in is None
         has_ln = ln_w is not None
         ldx = pad8(dq)
-        xb = SCRATCH.bf16(rows_q, dq, dev)
         mean = rstd = None
         if has_ln:
+            xb = SCRATCH.bf16(rows_q, dq, dev)
             mean = torch.empty(rows_q, device=dev)
             rstd = torch.empty(rows_q, device=dev)
             ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), xb, ldx, None, mean, rstd, rows_q, dq)
         else:
-            ops.cast_bf16(x, dq, xb, ldx, rows_q, dq)
+            xb = SCRATCH.memo_bf16(x, rows_q, dq)        # (its producer may have offered it: StepScratch.offer_bf16)
         m8, msb, msq = _mask_u8(mask)
         s_attn, s_res = SEEDS.next(), SEEDS.next()
         if self_att:
@@ -1537,7 +1537,10 @@ class ExpandGoalsFn(torch.autograd.Function):
         src = torch.empty(B * L, dtype=torch.int32, device=dev)
         ops.expand_goals_index(seg2, src, B, L)
         out = torch.empty(B, L, D, device=dev)
-        ops.gather_rows(goals.contiguous(), src, out, None, 0, B * L, D)
+        ob = SCRATCH.bf16(B * L, D, dev) if SCRATCH.armed else None        # (the goal attention's query operand: no cast launch)
+        ops.gather_rows(goals.contiguous(), src, out, ob, ob.shape[1] if ob is not None else 0, B * L, D)
+        if ob is not None:
+            SCRATCH.offer_bf16(out, B * L, D, ob)
         ctx.save_for_backward(src)
         ctx.cfg = (B, L, D)
         return out
@@ -1573,8 +1576,7 @@ class WorkerHeadFn(torch.autograd.Function):
         part = ShadowCache.split_part(K)
         ld = 3 * part
         xb = SCRATCH.zeroed_bf16(rows, ld, dev)                 # (padding columns K .. part of each block stay zero)
-        ops.cast_split3_bf16(x.contiguous(), d1, xb, ld, part, 2, rows, d1)
-        ops.cast_split3_bf16(gc.contiguous(), d2, xb, ld, part, 2, rows, d2, y_off=d1)
+        ops.cast_split3_bf16(x.contiguous(), d1, xb, ld, part, 2, rows, d1, x2=gc.contiguous(), ldx2=d2, cols2=d2)
         wb = SHADOWS.weight_split3(w)
         logp = torch.empty(B, L, V, device=dev)
         ops.gemm(xb, wb, rows, V, ld, lda=ld, ldb=ld, C_f32=logp, ldc=V, bias=b.detach())

@@ -293,11 +293,12 @@ def cast_bf16(x, ldx, y, ldy, rows, cols, scale=1.0, dropout_p=0.0, seed=0, y_of
                                            seed, _p(seed_dev), stream()), "bmhrl_cast_bf16")
 
 
-def cast_split3_bf16(x, ldx, y, ldy, part, lo_slot, rows, cols, y_off=0):
-    """y blocks [hi | . | .] of width `part`: bf16(x) in block 0, bf16(x - hi) in block lo_slot, hi again in the other"""
+def cast_split3_bf16(x, ldx, y, ldy, part, lo_slot, rows, cols, y_off=0, x2=None, ldx2=0, cols2=0):
+    """y blocks [hi | . | .] of width `part`: bf16(x) in block 0, bf16(x - hi) in block lo_slot, hi again in the other;
+    x2 (rows, cols2): a second source whose columns follow x's inside every block"""
     _need_cuda(x, y)
     _lib.check(_lib.load().bmhrl_cast_split3_bf16(x.data_ptr(), ldx, y.data_ptr() + 2 * y_off, ldy, part, lo_slot, rows, cols,
-                                                  stream()), "bmhrl_cast_split3_bf16")
+                                                  _p(x2), ldx2, cols2, stream()), "bmhrl_cast_split3_bf16")
 
 
 def cast_colsum_bf16(x, ldx, y, ldy, rows, cols, colsum, scale=1.0, dropout_p=0.0, seed=0, seed_dev=None, colsum_off=0,

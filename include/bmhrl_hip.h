@@ -248,8 +248,10 @@ int bmhrl_cast_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t r
  * model/bm_hrl_agent.py:463-466,483-484): hi = bf16(x), lo = bf16(x - hi); y gets three column blocks of width `part`:
  * block 0 = hi, block lo_slot (1 or 2) = lo, the other block = hi.  Activations use lo_slot 2, weights lo_slot 1, so that one
  * GEMM with K = 3 * part yields x_hi W_hi + x_hi W_lo + x_lo W_hi.  Padding columns (cols .. part) are not written. */
+/* x2 (optional): a second source whose cols2 columns follow x's cols in every block (the concatenated operand of the
+ * vocabulary head, cat[x, goal completion], in one launch) */
 int bmhrl_cast_split3_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part, int32_t lo_slot, int64_t rows,
-                           int32_t cols, bmhrl_stream_t stream);
+                           int32_t cols, const float* x2, int64_t ldx2, int32_t cols2, bmhrl_stream_t stream);
 
 /* bmhrl_cast_bf16 + column sums of the rounded result in one pass: colsum[n] += sum_m y[m][n] (fp32 atomics; colsum is
  * accumulated into, the caller zeroes it).  dY cast and bias gradient of one layer -- nn.Linear's db of

@@ -328,6 +328,9 @@ def test_split_operand_gemm(dev):
     ops.cast_split3_bf16(x1, K1, xb, 3 * part, part, 2, rows, K1)
     ops.cast_split3_bf16(x2, K2, xb, 3 * part, part, 2, rows, K2, y_off=K1)
     ops.cast_split3_bf16(w, K, wb, 3 * part, part, 1, N, K)
+    both = torch.zeros_like(xb)                               # the two sources in ONE launch == the two launches
+    ops.cast_split3_bf16(x1, K1, both, 3 * part, part, 2, rows, K1, x2=x2, ldx2=K2, cols2=K2)
+    assert torch.equal(both, xb)
     x = torch.cat([x1, x2], -1)
     hi = bf(x)
     assert torch.equal(xb[:, :K], hi) and torch.equal(xb[:, part:part + K], hi)

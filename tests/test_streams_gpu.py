@@ -51,8 +51,35 @@ def test_parallel_branches_do_not_change_results():
     p1, s1, l1, g1 = _run(True)
     assert torch.equal(s0, s1) and torch.equal(p0, p1) and l0 == l1
     assert g0.keys() == g1.keys() and len(g0) > 100
-    # gradients are accumulated with fp32 atomics (split-K weight gradients, column sums, LayerNorm dgamma/dbeta): their
-    # last bits depend on the arrival order in any run, so they are compared to fp32 accumulation noise; the floor keeps
-    # the analytically-zero key-bias gradients (pure noise of ~1e-9) out
+    # Default mode: sums that go through fp32 atomics (split-K products -- since r03 also two dX products, so the order noise
+    # reaches the activation gradients and, through a bf16 rounding that flips, shows as ~1e-3 on the cancellation-prone
+    # key / query weights of the first encoder layer) depend on the arrival order in ANY run, serial or not: here only a
+    # coarse bound; the exact statement is the deterministic-mode test below.
     worst = max(float((g0[k] - g1[k]).norm() / (g0[k].norm() + 1e-6 * g0[k].numel() ** 0.5)) for k in g0)
-    assert worst < 1e-5, worst
+    assert worst < 5e-3, worst
+
+
+_DET_STREAMS = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests.test_streams_gpu import _run
+p0, s0, l0, g0 = _run(False)
+p1, s1, l1, g1 = _run(True)
+bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+assert torch.equal(p0, p1) and torch.equal(s0, s1) and l0 == l1 and not bad, bad[:5]
+print("identical", len(g0))
+"""
+
+
+def test_parallel_branches_are_exact_in_deterministic_mode():
+    """BMHRL_DETERMINISTIC=1 (ordered sums): forward outputs, loss and EVERY gradient with the side streams == without them,
+    bit for bit -- the branches only change the issue order."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMHRL_DETERMINISTIC="1")
+    r = subprocess.run([sys.executable, "-c", _DET_STREAMS, root], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "identical" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
