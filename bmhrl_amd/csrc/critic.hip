@@ -306,6 +306,103 @@ __global__ __launch_bounds__(256) void rnn_wave_kernel(const RnnTable tab, int n
   }
 }
 
+// ---- the same wavefront cell on the f32 matrix pipe (r03, default at chunk 1).  The VALU cell above is bound by its LDS
+// reads (one x value per two FMAs) and by the serial order load -> project -> load -> recur; here a block owns RW_UNITS = 16
+// hidden units and 16 batch rows and runs 16 waves: wave (k half, pass, gate) multiplies the 16 rows of ONE gate of ONE
+// matrix (pass 0: W_ih . x_t, pass 1: W_hh . h_{t-1}) over one half of k with v_mfma_f32_16x16x4_f32 (fp32 in, fp32
+// accumulate: IEEE products and sums, only the order of a row's sum differs from the k-ascending chain).  Lane (r = lane &
+// 15, q = lane >> 4) loads 16 bytes of weight row r at k = 16 step + 4 q straight from global memory (four lanes cover 64
+// contiguous bytes) and reads the 16 bytes of batch row r at the same k from LDS: element e of both feeds MFMA e of the
+// step, so the k mapping of A and B agree.  ALL of a wave's weight pieces (<= RW_STEPS) are requested before anything else:
+// one memory latency per launch, passing under the x / h staging.  Every weight byte is read once per launch, an x value
+// read from LDS feeds 16 rows; the matrix pipe's 256 flop / clock / CU (the VALU's packed rate) is the floor: ~4 us.
+constexpr int RW_UNITS = 16, RW_LD = MAXH + 4;      // row stride = 4 (mod 32) banks: the 16-byte reads of the 16 batch rows are 2-way
+constexpr int RW_STEPS = (MAXH / 16 + 1) / 2;       // 16-column steps of one k half
+
+__global__ __launch_bounds__(1024) void rnn_wave_mfma_kernel(const RnnTable tab, int B, int L, int H, int s) {
+  __shared__ __attribute__((aligned(16))) float sh_in[2][16][RW_LD];   // x_t | h_{t-1}, zero behind the last column
+  __shared__ float sh_g[2][2][4][RW_UNITS][17];                        // [k half][pass][gate][unit][batch row]
+  const int layer = blockIdx.z, t = s - layer;
+  if (t < 0 || t >= L) return;                                         // uniform for the block
+  const bmhrl_rnn_layer& P = tab.l[layer];
+  const int GATES = P.gates, K1 = P.in_dim;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int half = wave >> 3, pass = (wave >> 2) & 1, gate = wave & 3;
+  const int u0 = blockIdx.x * RW_UNITS, b0 = blockIdx.y * 16;
+  const bool busy = gate < GATES && (pass == 0 || t > 0);              // uniform for the wave
+  const int K = pass == 0 ? K1 : H, nsteps = (K + 15) / 16, nh = (nsteps + 1) / 2;
+  const int step0 = half * nh, n = busy ? min(nh, nsteps - step0) : 0;
+  const int r = lane & 15, kq = lane >> 4;
+  const bool row_ok = u0 + r < H;
+  const float* wrow = (pass == 0 ? P.w_ih : P.w_hh) + ((long)gate * H + (row_ok ? u0 + r : 0)) * K + 16 * step0 + 4 * kq;
+  f32x4 piece[RW_STEPS];
+#pragma unroll
+  for (int i = 0; i < RW_STEPS; ++i)
+    piece[i] = (i < n && row_ok && 16 * (step0 + i) + 4 * kq < K) ? *reinterpret_cast<const f32x4*>(wrow + 16 * i)
+                                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int C4 = RW_LD / 4;
+  for (int i = tid; i < 2 * 16 * C4; i += 1024) {
+    const int img = i / (16 * C4), rem = i - img * (16 * C4), rr = rem / C4, c4 = (rem - rr * C4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (b0 + rr < B) {
+      if (img == 0) {
+        if (c4 < K1) v = *reinterpret_cast<const f32x4*>(P.in_seq + ((long)(b0 + rr) * L + t) * P.in_ld + c4);
+      } else if (t > 0 && c4 < H) {
+        v = *reinterpret_cast<const f32x4*>(P.h[(t + 1) & 1] + (long)(b0 + rr) * H + c4);
+      }
+    }
+    *reinterpret_cast<f32x4*>(&sh_in[img][rr][c4]) = v;
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* xb = &sh_in[pass][r][16 * step0 + 4 * kq];
+#pragma unroll
+  for (int i = 0; i < RW_STEPS; ++i) {
+    if (i < n) {                                                       // uniform
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xb + 16 * i);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(piece[i][0], x[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(piece[i][1], x[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(piece[i][2], x[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(piece[i][3], x[3], acc, 0, 0, 0);
+    }
+  }
+  if (gate < GATES) {                                                  // accumulator: unit 4 q + i, batch row r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sh_g[half][pass][gate][4 * kq + i][r] = acc[i];
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int ul = tid >> 4, bl = tid & 15, u = u0 + ul, b = b0 + bl;
+    if (u < H && b < B) {
+      float hn;
+      if (GATES == 4) {                                                // same association as the VALU cell: (x part + (b_ih + b_hh)) + h part
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          pre[g] = ((sh_g[0][0][g][ul][bl] + sh_g[1][0][g][ul][bl]) + (P.b_ih[(long)g * H + u] + P.b_hh[(long)g * H + u])) +
+                   (sh_g[0][1][g][ul][bl] + sh_g[1][1][g][ul][bl]);
+        const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
+        const float c = gf * (t > 0 ? P.c[(t + 1) & 1][(long)b * H + u] : 0.f) + gi * gg;
+        P.c[t & 1][(long)b * H + u] = c;
+        hn = go * tanhf(c);
+      } else {
+        float xp[3], hp[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          xp[g] = (sh_g[0][0][g][ul][bl] + sh_g[1][0][g][ul][bl]) + P.b_ih[(long)g * H + u];
+          hp[g] = (sh_g[0][1][g][ul][bl] + sh_g[1][1][g][ul][bl]) + P.b_hh[(long)g * H + u];
+        }
+        const float rg = sigmoidf_(xp[0] + hp[0]);
+        const float z = sigmoidf_(xp[1] + hp[1]);
+        const float nn = tanhf(xp[2] + rg * hp[2]);
+        hn = (1.f - z) * nn + z * sh_in[1][bl][u];                     // (zero at t = 0)
+      }
+      P.h[t & 1][(long)b * H + u] = hn;
+      P.seq_out[((long)b * L + t) * H + u] = P.arelu_alpha ? arelu_(hn, P.arelu_alpha[0], P.arelu_beta[0]) : hn;
+    }
+  }
+}
+
 // labels[row] = sigmoid(lin_w . x[row] + lin_b) > thr ; also the raw score (for tests / callers)
 __global__ void critic_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                    float thr, float* __restrict__ score, int32_t* __restrict__ labels, long rows, int H) {
@@ -365,6 +462,13 @@ extern "C" int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_laye
     BMHRL_CHECK_ARG((p.arelu_alpha == nullptr) == (p.arelu_beta == nullptr));
     BMHRL_CHECK_ARG((((uintptr_t)p.w_ih | (uintptr_t)p.w_hh | (uintptr_t)p.in_seq | (uintptr_t)p.h[0] | (uintptr_t)p.h[1]) & 15) == 0);
     tab.l[i] = p;
+  }
+  static const bool mfma = !(getenv("BMHRL_RNN_MFMA") && atoi(getenv("BMHRL_RNN_MFMA")) == 0);
+  if (chunk == 1 && mfma) {                             // the matrix-pipe cell: one launch per diagonal, 16 waves per block
+    const dim3 grid((unsigned)((H + RW_UNITS - 1) / RW_UNITS), (unsigned)((B + 15) / 16), (unsigned)n_layers), block(1024);
+    for (int s = 0; s < L + n_layers - 1; ++s)
+      hipLaunchKernelGGL(rnn_wave_mfma_kernel, grid, block, 0, S_(stream), tab, B, L, H, s);
+    return hip_status(hipGetLastError());
   }
   static const int spt = getenv("BMHRL_RNN_SPT") ? atoi(getenv("BMHRL_RNN_SPT")) : 2;     // gate rows per thread (tuning aid: 1)
   static const bool vargrid = getenv("BMHRL_RNN_VARGRID") && atoi(getenv("BMHRL_RNN_VARGRID")) != 0;

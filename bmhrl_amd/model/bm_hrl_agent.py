@@ -256,8 +256,9 @@ class BMFusion(nn.Module):
 
 class SegmentCritic(nn.Module):
     """Frozen LSTM(4) -> AReLU -> GRU(2) -> AReLU -> Linear segment scorer, reference :186-215.
-    On the GPU it runs on the fp32 HIP kernels of csrc/critic.hip (score_and_labels: f32-MFMA input projections, one
-    launch per time step, fused score / threshold head) so the int segment labels equal the reference's exactly; the
+    On the GPU it runs on the fp32 HIP kernels of csrc/critic.hip (score_and_labels: one launch per (layer + time)
+    diagonal, both matrices of a cell on the f32-input MFMA, fused score / threshold head) so the int segment labels equal
+    the reference's exactly; the
     nn.LSTM / nn.GRU modules only hold the parameters (reference state-dict keys) and serve CPU tensors.
     `cfg.rl_critic_path` is loaded when given; None leaves the (frozen) default initialisation in place."""
 

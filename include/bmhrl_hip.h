@@ -401,7 +401,8 @@ typedef struct bmhrl_rnn_layer {
   float* xproj;                                           /* (B, L, gates*H) scratch, needed when chunk > 1 */
 } bmhrl_rnn_layer;
 int bmhrl_rnn_wavefront(const bmhrl_rnn_layer* layers, int32_t n_layers, int32_t B, int32_t L, int32_t H,
-                        int32_t chunk /* time steps a layer trails the one below: W_ih is read once per chunk */,
+                        int32_t chunk /* time steps a layer trails the one below: W_ih is read once per chunk; 1 = the
+                                         plain diagonal, which runs the matrix-pipe cell (v_mfma_f32_16x16x4_f32) */,
                         bmhrl_stream_t stream);
 int bmhrl_critic_head(const float* x, const float* w, const float* b, float threshold, float* score, int32_t* labels,
                       int64_t rows, int32_t H, bmhrl_stream_t stream);
