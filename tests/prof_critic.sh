@@ -6,11 +6,14 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $R/tests/bench
 python3 - <<PY
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("$OUT/t/**/*_kernel_trace.csv", recursive=True)[0])))
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if "rnn_wave" in r["Kernel_Name"])
-last = ev[-45:]            # the final replay of the chunk-3 configuration
-d = [(e - s) / 1e3 for s, e, _ in last]
-g = [(last[i + 1][0] - last[i][1]) / 1e3 for i in range(44)]
-print("durations us:", " ".join(f"{x:.0f}" for x in d))
-print("gaps us     :", " ".join(f"{x:.1f}" for x in g))
-print("sum dur %.0f us, sum gaps %.0f us" % (sum(d), sum(g)))
+for name, n in (("rnn_wave_mfma", 35), ("rnn_wave_kernel", 45)):   # the final replay of the chunk-1 (matrix pipe) / chunk-3 (VALU) form
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if name in r["Kernel_Name"])
+    if len(ev) < n:
+        continue
+    last = ev[-n:]
+    d = [(e - s) / 1e3 for s, e in last]
+    g = [(last[i + 1][0] - last[i][1]) / 1e3 for i in range(n - 1)]
+    print(name, "durations us:", " ".join(f"{x:.1f}" for x in d))
+    print(name, "gaps us     :", " ".join(f"{x:.1f}" for x in g))
+    print(name, "sum dur %.0f us, sum gaps %.0f us" % (sum(d), sum(g)))
 PY
