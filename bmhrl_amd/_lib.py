@@ -99,6 +99,7 @@ PROTOTYPES = {
     "bmhrl_smooth_kl_bwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i32, ptr, i64, ptr, i64, i32, ptr],
     "bmhrl_token_loss_reduce": [ptr, ptr, i64, i64, ptr, f32, ptr, ptr, ptr],
     "bmhrl_log_softmax_bwd": [ptr, ptr, i64, ptr, i64, i64, i32, ptr],
+    "bmhrl_head_loss": [ptr, i64, ptr, f32, i32, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, i64, i32, ptr],
     "bmhrl_smooth_kl_amp_grad": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, i64, i32, ptr],
     "bmhrl_sample_tokens": [ptr, i64, ptr, ptr, i64, i32, i32, u64, ptr, i64, ptr],
     "bmhrl_reinforce_fwd": [ptr, i64, i32, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],

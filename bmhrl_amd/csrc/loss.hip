@@ -247,6 +247,114 @@ __global__ void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const fl
   for (int c = threadIdx.x; c < V; c += blockDim.x) gb[row * ldg + c] = (bf16_t)(d[c] - __expf(lp[c]) * s);
 }
 
+// The warmstart step's whole loss tail in ONE pass over the logits (r03): log-softmax in place (the row stays in registers,
+// as in log_softmax_vec_kernel), the label-smoothing row sum (smooth_kl_fwd_kernel), the gradient w.r.t. the logits as the
+// bf16 operand of the head's backward (smooth_kl_bwd_kernel with wrt_logits: same expressions, same values) and the loops'
+// reduction loss = weight * sum(rows) / n_tokens: every block counts the tokens itself (rows is a few hundred) and adds its row
+// to a fixed-point sum; the block that arrives last writes the loss and re-arms the four sync words (deterministic).
+// `dloss` is the gradient the caller will hand to backward() (a constant 1 in the trainer): the gradient is final here.
+template <int NV>
+__global__ __launch_bounds__(256) void head_loss_kernel(float* __restrict__ x, long ld, const int64_t* __restrict__ trg,
+                                                        float smoothing, int pad, const float* __restrict__ weight, float factor,
+                                                        const float* __restrict__ dloss, float* __restrict__ row_loss,
+                                                        float* __restrict__ out, bf16_t* __restrict__ gb, long ldg,
+                                                        unsigned* __restrict__ sync, long rows, int V) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  float* r = x + row * ld;
+  f32x4 v[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (threadIdx.x + 256 * i);
+    v[i] = c < V ? *reinterpret_cast<const f32x4*>(r + c) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    m = fmaxf(m, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+  }
+  m = block_max(m, red);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += __expf(v[i][j] - m);
+  s = block_sum(s, red);
+  const float lse = m + __logf(s);
+  const RowTarget T = make_target(r, trg, nullptr, nullptr, nullptr, smoothing, pad, -1, row, rows, V, nullptr);
+  float s1 = 0.f, lp_t = 0.f, lp_pad = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (threadIdx.x + 256 * i);
+    if (c < V) {
+      v[i] = v[i] - f32x4{lse, lse, lse, lse};
+      *reinterpret_cast<f32x4*>(r + c) = v[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1 += v[i][j];
+        if (c + j == T.t) lp_t = v[i][j];
+        if (c + j == T.pad) lp_pad = v[i][j];
+      }
+    }
+  }
+  float cnt = 0.f;
+  for (long i = threadIdx.x; i < rows; i += 256) cnt += trg[i] != pad ? 1.f : 0.f;
+  // one exchange for the four sums (lp_t / lp_pad: one thread holds the value, the others 0)
+  s1 = wave_sum(s1); lp_t = wave_sum(lp_t); lp_pad = wave_sum(lp_pad); cnt = wave_sum(cnt);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    const int wv = threadIdx.x >> 6;
+    red[wv] = s1; red[4 + wv] = lp_t; red[8 + wv] = lp_pad; red[12 + wv] = cnt;
+  }
+  __syncthreads();
+  s1 = (red[0] + red[1]) + (red[2] + red[3]);
+  lp_t = (red[4] + red[5]) + (red[6] + red[7]);
+  lp_pad = (red[8] + red[9]) + (red[10] + red[11]);
+  cnt = (red[12] + red[13]) + (red[14] + red[15]);
+  const float w = (weight ? weight[0] : 1.f) / (cnt * factor);
+  const float scale = dloss ? w * dloss[0] : w;
+  // gradient: the expressions of smooth_kl_bwd_kernel without a sampled token
+  const int ns = 1 + (T.pad != T.t);
+  const float d0 = T.zero_row ? T.eps : T.u + T.eps;
+  float dsum = (float)(V - ns) * d0 + T.at(T.t);
+  if (T.pad != T.t) dsum += T.at(T.pad);
+  const float G = -dsum;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (threadIdx.x + 256 * i);
+    if (c < V) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float g = -T.at(c + j) - __expf(v[i][j]) * G;
+        g *= scale;
+        o[j] = (bf16_t)g;
+      }
+      *reinterpret_cast<bf16x4*>(gb + row * ldg + c) = o;
+    }
+  }
+  if (threadIdx.x != 0) return;
+  // row sum: the closed form of smooth_kl_fwd_kernel
+  float loss = xlogx(T.at(T.t)) - T.at(T.t) * lp_t, lp_special = lp_t;
+  if (T.pad != T.t) {
+    loss += xlogx(T.at(T.pad)) - T.at(T.pad) * lp_pad;
+    lp_special += lp_pad;
+  }
+  loss += (float)(V - ns) * xlogx(d0) - d0 * (s1 - lp_special);
+  row_loss[row] = loss;
+  // sum over the rows without a second launch and without a fence (a release fence writes this XCD's L2 back: 480 of them
+  // cost 16 us): the rows are added as 2^-32 fixed point with a 64-bit integer atomic -- associative, so the sum does not
+  // depend on the order the blocks arrive in -- and the block whose counter increment comes last reads the total.  An
+  // atomic that has RETURNED has been performed where all XCDs see it, so a block's increment follows its own addition.
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(sync);
+  const long long fixed = (long long)((double)loss * 4294967296.0);
+  const unsigned long long before = atomicAdd(acc, (unsigned long long)fixed);
+  asm volatile("" : : "v"((unsigned)before) : "memory");
+  if (atomicAdd(sync + 2, 1u) != (unsigned)(rows - 1)) return;
+  const long long total = (long long)atomicAdd(acc, 0ull);
+  out[0] = (float)((double)total * (1.0 / 4294967296.0)) * w;
+  out[1] = w;
+  atomicExch(acc, 0ull);
+  atomicExch(sync + 2, 0u);
+}
+
 // Inverse-CDF categorical sample with one uniform per row (or arg-max), block per row.
 // loss = weight * sum(row_loss) / n_tokens and scale = weight / n_tokens (what the backward multiplies every row by), with
 // n_tokens = #(trg != pad): the reduction epoch_loops/captioning_bmrl_loops.py:1156-1158 (warmstart) / :846-847,859 (RL, with
@@ -402,6 +510,21 @@ extern "C" int bmhrl_token_loss_reduce(const float* row_loss, const int64_t* trg
   BMHRL_CHECK_ARG(row_loss && trg && loss && scale && rows > 0 && factor > 0.f);
   hipLaunchKernelGGL(token_loss_reduce_kernel, dim3(1), dim3(256), 0, S_(stream), row_loss, trg, (long)rows, pad_idx, weight, factor,
                      loss, scale);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_head_loss(float* logits, int64_t ld, const int64_t* trg, float smoothing, int32_t pad_idx, const float* weight,
+                               float factor, const float* dloss, float* row_loss, float* loss_scale, void* dlogits_bf16,
+                               int64_t ldg, uint32_t* counter, int64_t rows, int32_t V, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(logits && trg && row_loss && loss_scale && dlogits_bf16 && counter && rows > 0 && V > 2 && factor > 0.f);
+  BMHRL_CHECK_ARG(V % 4 == 0 && ld % 4 == 0 && ld >= V && ldg % 4 == 0 && ldg >= V && V <= 256 * 4 * 12);
+  BMHRL_CHECK_ARG((((uintptr_t)logits & 15) | ((uintptr_t)dlogits_bf16 & 7) | ((uintptr_t)counter & 7)) == 0);
+  const int nv = (V + 1023) / 1024;
+#define HL(NV_) hipLaunchKernelGGL(head_loss_kernel<NV_>, dim3((unsigned)rows), dim3(256), 0, S_(stream), logits, (long)ld, trg,    \
+                                   smoothing, pad_idx, weight, factor, dloss, row_loss, loss_scale, (bf16_t*)dlogits_bf16, (long)ldg, \
+                                   counter, (long)rows, V)
+  if (nv <= 2) HL(2); else if (nv <= 4) HL(4); else if (nv <= 8) HL(8); else HL(12);
+#undef HL
   return hip_status(hipGetLastError());
 }
 

@@ -1558,6 +1558,24 @@ class ExpandGoalsFn(torch.autograd.Function):
 # d logits a TokenLossFn(sole_consumer=True) computed in place of the fp32 d log-probs it returns (keyed by that tensor)
 _HEAD_LOGP = {}
 _GRAD_TWIN = {}
+# The warmstart trainer announces its loss before the agent's forward (request_head_loss): the worker head then runs the
+# log-softmax, the label-smoothing row sums, the token-normalised loss and d logits as ONE launch (ops.head_loss) and
+# TokenLossFn, finding the result under the log-probs' address, launches nothing -- forward or backward.
+_HEAD_LOSS_REQ = []
+_HEAD_LOSS_OUT = {}
+_HEAD_LOSS_COUNTER = {}
+FUSED_HEAD_LOSS = os.environ.get("BMHRL_FUSED_HEAD_LOSS", "1") == "1"
+
+
+def request_head_loss(trg, smoothing, pad_idx, factor, weight, dloss):
+    """trg (B, L) int64 targets, weight: device scalar or None, dloss: the tensor backward() will be given (a constant)."""
+    del _HEAD_LOSS_REQ[:]
+    if FUSED_HEAD_LOSS and trg.is_cuda:
+        _HEAD_LOSS_REQ.append((trg, float(smoothing), int(pad_idx), float(factor), weight, dloss))
+
+
+def cancel_head_loss():
+    del _HEAD_LOSS_REQ[:]
 
 
 class WorkerHeadFn(torch.autograd.Function):
@@ -1580,7 +1598,21 @@ class WorkerHeadFn(torch.autograd.Function):
         wb = SHADOWS.weight_split3(w)
         logp = torch.empty(B, L, V, device=dev)
         ops.gemm(xb, wb, rows, V, ld, lda=ld, ldb=ld, C_f32=logp, ldc=V, bias=b.detach())
-        ops.log_softmax_(logp, V, rows, V)
+        req = _HEAD_LOSS_REQ.pop() if _HEAD_LOSS_REQ else None
+        _HEAD_LOSS_OUT.clear()
+        gb = SCRATCH.bf16(rows, V, dev) if req is not None else None
+        if gb is not None and req[0].numel() == rows and ops.head_loss_ok(V, V, gb.shape[1]):
+            trg, smoothing, pad_idx, factor, weight, dloss = req
+            counter = _HEAD_LOSS_COUNTER.get(dev)
+            if counter is None:
+                counter = _HEAD_LOSS_COUNTER[dev] = torch.zeros(4, dtype=torch.int32, device=dev)   # 64-bit sum, arrival count
+            trg = trg.contiguous().view(-1)
+            row_loss = torch.empty(rows, device=dev)
+            out = torch.empty(2, device=dev)                 # [loss, scale]
+            ops.head_loss(logp, V, trg, smoothing, pad_idx, weight, factor, dloss, row_loss, out, gb, gb.shape[1], counter, rows, V)
+            _HEAD_LOSS_OUT[logp.data_ptr()] = (req, trg, out, gb)
+        else:
+            ops.log_softmax_(logp, V, rows, V)
         ctx.save_for_backward(xb, w, logp)
         ctx.cfg = (B, L, d1, d2, V)
         if len(_HEAD_LOGP) > 64:
@@ -1688,6 +1720,21 @@ class TokenLossFn(torch.autograd.Function):
         rows = B * S
         dev = logp.device
         ctx.twin = bool(sole_consumer) and logp.is_contiguous() and _HEAD_LOGP.get(logp.data_ptr()) == (logp._version, tuple(logp.shape))
+        ctx.fused = None
+        done = _HEAD_LOSS_OUT.pop(logp.data_ptr(), None) if ctx.twin and biased_trg is None else None
+        _HEAD_LOSS_OUT.clear()
+        if done is not None:
+            (r_trg, r_s, r_pad, r_f, r_w, r_dl), trg_flat, out, gb = done
+            if (r_trg.data_ptr() == trg.data_ptr() and r_trg.shape == trg.shape and r_s == float(smoothing) and r_pad == int(pad_idx)
+                    and r_f == float(factor) and (r_w is weight or (r_w is not None and weight is not None
+                                                                     and r_w.data_ptr() == weight.data_ptr()))):
+                # the head already ran the whole tail (ops.head_loss): nothing to launch here
+                ctx.fused = (gb, None if r_dl is None else r_dl.data_ptr())
+                ctx.save_for_backward(logp, trg_flat, None, None, None, out)
+                ctx.cfg = (B, S, V, smoothing, pad_idx)
+                return out[0]
+            # (announced for other targets / parameters than this call's: the log-probs are log-probs all the same; the
+            # unfused kernels below take over)
         logp = logp.contiguous()
         trg = trg.contiguous().view(-1)
         bt = biased_trg.contiguous().view(-1) if biased_trg is not None else None
@@ -1709,9 +1756,11 @@ class TokenLossFn(torch.autograd.Function):
         rows = B * S
         g = torch.empty(rows, V, device=logp.device)
         dl = dloss.reshape(1)                                # (one element; multiplied in by the kernel)
-        if ctx.twin:
+        if ctx.fused is not None and ctx.fused[1] == dloss.data_ptr():
+            _GRAD_TWIN[g.data_ptr()] = ctx.fused[0]          # d logits were final in the forward
+        elif ctx.twin:
             # g stays unwritten: WorkerHeadFn.backward finds the bf16 d logits under g's address
-            gb = SCRATCH.bf16(rows, V, logp.device)
+            gb = ctx.fused[0] if ctx.fused is not None else SCRATCH.bf16(rows, V, logp.device)
             ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], gb, gb.shape[1], None, rows, V,
                               wrt_logits=True, loss_scale2=dl)
             _GRAD_TWIN[g.data_ptr()] = gb

@@ -433,6 +433,19 @@ def token_loss_reduce(row_loss, trg, rows, pad_idx, weight, factor, loss, scale)
                                                    loss.data_ptr(), scale.data_ptr(), stream()), "bmhrl_token_loss_reduce")
 
 
+def head_loss_ok(V, ld, ldg):
+    return V % 4 == 0 and ld % 4 == 0 and ldg % 4 == 0 and 2 < V <= 12288
+
+
+def head_loss(logits, ld, trg, smoothing, pad_idx, weight, factor, dloss, row_loss, loss_scale, g_bf16, ldg, counter, rows, V):
+    """log-softmax in place + label-smoothing row sums + the loops' token-normalised loss (loss_scale = [loss, scale]) + bf16
+    d logits for the incoming gradient `dloss` (device scalar or None = 1), one launch"""
+    _need_cuda(logits, trg, row_loss, loss_scale, g_bf16, counter)
+    _lib.check(_lib.load().bmhrl_head_loss(logits.data_ptr(), ld, trg.data_ptr(), smoothing, pad_idx, _p(weight), factor, _p(dloss),
+                                           row_loss.data_ptr(), loss_scale.data_ptr(), g_bf16.data_ptr(), ldg, counter.data_ptr(),
+                                           rows, V, stream()), "bmhrl_head_loss")
+
+
 def log_softmax_bwd(dlogp, logp, ld, g_bf16, ldg, rows, V):
     _lib.check(_lib.load().bmhrl_log_softmax_bwd(dlogp.data_ptr(), logp.data_ptr(), ld, g_bf16.data_ptr(), ldg, rows, V, stream()),
                "bmhrl_log_softmax_bwd")

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, synthetic as syn
-from .functional import SCRATCH, SEEDS, SHADOWS, ScratchState, TokenLossFn
+from .functional import SCRATCH, SEEDS, SHADOWS, ScratchState, TokenLossFn, cancel_head_loss, request_head_loss
 from .loss.biased_kl import BiasedKL
 from .loss.label_smoothing import LabelSmoothing
 from .model.bm_hrl_agent import BMHrlAgent, BMManagerValueFunction, BMWorkerValueFunction
@@ -421,11 +421,19 @@ class CaptionTrainer:
                 masks = {"V_mask": vm2[:B], "A_mask": am2[:B], "C_mask": cm2[:B], "_pair": (cm2, am2, vm2)}
             else:
                 masks = make_masks(fs, trg_in, self.modality, self.pad_idx)
-        pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
+        fused_tail = self.phase == "warmstart" and rl is None and trg_y.is_cuda and torch.is_grad_enabled()
+        w = self.loss_weight if self._world_scale() != 1.0 else None
+        if fused_tail:
+            # the worker head runs log-softmax, loss and d logits as one launch (functional.request_head_loss); the gradient
+            # this trainer starts every backward from is the constant of _unit_grad()
+            request_head_loss(trg_y, float(self.criterion.smoothing), int(self.criterion.pad_idx), 1.0, w, self._unit_grad_dev(trg_y.device))
+        try:
+            pred, w_feat, m_feat, goals, seg = self.agent(((fs["rgb"], fs["flow"]), fs["audio"]), trg_in, masks)
+        finally:
+            cancel_head_loss()
         if self.phase == "warmstart" and rl is None and pred.is_cuda:
             # sum(LabelSmoothing) / n_tokens (x the rank's token weight) as one node: functional.TokenLossFn; the
             # prediction has no other differentiated consumer here, so the head's backward takes d logits from that node
-            w = self.loss_weight if self._world_scale() != 1.0 else None
             return TokenLossFn.apply(pred, trg_y, None, None, None, float(self.criterion.smoothing), int(self.criterion.pad_idx),
                                      1.0, w, True), pred
         loss_mask = trg_y != self.pad_idx
@@ -497,9 +505,14 @@ class CaptionTrainer:
 
     def _unit_grad(self, loss):
         """d loss / d loss as a constant kept for the trainer's lifetime (autograd otherwise fills a fresh one every step)"""
+        if loss.dtype == torch.float32:
+            return self._unit_grad_dev(loss.device)
+        return torch.ones((), device=loss.device, dtype=loss.dtype)
+
+    def _unit_grad_dev(self, device):
         one = self.__dict__.get("_one")
-        if one is None or one.device != loss.device or one.dtype != loss.dtype:
-            one = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        if one is None or one.device != device:
+            one = self._one = torch.ones((), device=device, dtype=torch.float32)
         return one
 
     # ------------------------------------------------------------------ whole-step HIP graph

@@ -349,6 +349,17 @@ int bmhrl_smooth_kl_bwd(const float* logp, int64_t ld, const int64_t* trg, const
  * factor) is what bmhrl_smooth_kl_bwd takes as loss_scale.  weight: optional device scalar (data-parallel token weight). */
 int bmhrl_token_loss_reduce(const float* row_loss, const int64_t* trg, int64_t rows, int64_t pad_idx, const float* weight,
                             float factor, float* loss, float* scale, bmhrl_stream_t stream);
+/* The warmstart loss tail as one launch (r03): log_softmax in place over `logits` (model/bm_hrl_agent.py:463-466), the
+ * LabelSmoothing row sums (loss/label_smoothing.py:12-32), loss_scale[0] = weight * sum(rows) / (n_tokens * factor) and
+ * loss_scale[1] = weight / (n_tokens * factor) (epoch_loops/captioning_bmrl_loops.py:1156-1158), and d loss / d logits as
+ * bf16 (loss.backward() of the loops, through the log-softmax) for the gradient `dloss` (device scalar or NULL = 1) the
+ * caller will pass to backward.  V % 4 == 0, V <= 12288.  `counter`: four zero-initialised 32-bit words (8-byte aligned)
+ * the kernel re-arms: the rows are summed as 2^-32 fixed point with integer atomics (order independent: deterministic), the
+ * block that arrives last writes loss_scale.  Same values as bmhrl_log_softmax + bmhrl_smooth_kl_fwd +
+ * bmhrl_token_loss_reduce + bmhrl_smooth_kl_bwd(wrt_logits) up to the rounding of the loss's sums. */
+int bmhrl_head_loss(float* logits, int64_t ld, const int64_t* trg, float smoothing, int32_t pad_idx, const float* weight,
+                    float factor, const float* dloss, float* row_loss, float* loss_scale, void* dlogits_bf16, int64_t ldg,
+                    uint32_t* counter, int64_t rows, int32_t V, bmhrl_stream_t stream);
 int bmhrl_log_softmax_bwd(const float* dlogp, const float* logp, int64_t ld, void* dlogits_bf16, int64_t ldg,
                           int64_t rows, int32_t V, bmhrl_stream_t stream);
 /* out[row] = d rowloss / d log(raw amplitude) (0 where clamp(., 0, 1) is active): the share of the gradient that reaches the

@@ -790,3 +790,45 @@ def test_criteria_unreduced_form_equals_the_reference_outputs(dev, golden):
     assert rel_err(bkl.unreduced(lp, T(g["trg"]), T(g["sampled"]), T(g["bkl_raw_amp"])), T(g["bkl_raw"])) < 1e-5
     # and the row sums the training path uses are the sums of exactly these rows
     assert rel_err(ls(lp, T(g["trg"])).view(-1), T(g["ls"]).sum(-1)) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,V,pad_rows", [(480, 10172, (3, 7, 479)), (7, 300, (0, 2)), (5, 2048, ()), (16, 4096, (0,))])
+def test_head_loss_one_launch_equals_the_four_kernels(rows, V, pad_rows):
+    """ops.head_loss (log-softmax + label-smoothing rows + token-normalised loss + bf16 d logits, one launch) against
+    log_softmax_ + smooth_kl_fwd + token_loss_reduce + smooth_kl_bwd(wrt_logits): log-probs, scale and the gradient bit for
+    bit, the loss up to the order of a row's fp32 sum; twice in a row (the kernel re-arms its counter)"""
+    from bmhrl_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + V)
+    logits = (torch.randn(rows, V, generator=g) * 3).to(dev)
+    trg = torch.randint(2, V, (rows,), generator=g).to(dev)
+    pad = 1
+    for r in pad_rows:
+        trg[r] = pad
+    weight = torch.tensor([0.7], device=dev)
+    dl = torch.tensor(1.25, device=dev)
+    ref = logits.clone()
+    ops.log_softmax_(ref, V, rows, V)
+    row_loss = torch.empty(rows, device=dev)
+    ops.smooth_kl_fwd(ref, V, trg, None, None, None, 0.7, pad, -1, row_loss, None, rows, V)
+    out = torch.empty(2, device=dev)
+    ops.token_loss_reduce(row_loss, trg, rows, pad, weight, 1.0, out[0:1], out[1:2])
+    ldg = (V + 7) // 8 * 8
+    gb = torch.zeros(rows, ldg, dtype=torch.bfloat16, device=dev)
+    ops.smooth_kl_bwd(ref, V, trg, None, None, None, 0.7, pad, -1, out[1:2], gb, ldg, None, rows, V, wrt_logits=True,
+                      loss_scale2=dl.reshape(1))
+    counter = torch.zeros(4, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        x = logits.clone()
+        rl2 = torch.empty(rows, device=dev)
+        out2 = torch.full((2,), float("nan"), device=dev)
+        gb2 = torch.zeros(rows, ldg, dtype=torch.bfloat16, device=dev)
+        ops.head_loss(x, V, trg, 0.7, pad, weight, 1.0, dl, rl2, out2, gb2, ldg, counter, rows, V)
+        torch.cuda.synchronize()
+        assert int(counter.abs().sum()) == 0
+        assert torch.equal(x, ref)
+        assert torch.equal(out2[1], out[1])
+        assert torch.equal(gb2, gb)
+        assert float((rl2 - row_loss).abs().max()) <= 2e-6 * float(row_loss.abs().max())
+        assert abs(float(out2[0]) - float(out[0])) <= 2e-6 * abs(float(out[0]))

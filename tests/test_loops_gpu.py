@@ -148,6 +148,46 @@ def test_unzeroed_gradient_arena_is_only_ever_overwritten(setup):
     assert float((p0 - p1).norm() / p0.norm()) < 3e-3
 
 
+def test_fused_head_loss_trains_like_the_four_kernel_tail(setup):
+    """The warmstart step with the worker head's one-launch loss tail (functional.request_head_loss -> ops.head_loss) against
+    the same step with log_softmax + smooth_kl_fwd + token_loss_reduce + smooth_kl_bwd: the fused form must actually run
+    (once per step, TokenLossFn launching nothing), and losses / weights must agree (the gradient is bit-identical, the
+    loss differs by the order of a row's fp32 sum; the comparison bound is that of two runs with atomics)."""
+    from bmhrl_amd import functional as F, ops
+    from bmhrl_amd.train import CaptionTrainer
+    cfg, ds, loader, agent, wv, ls, bkl, dev = setup
+    b = ds.batches[0]
+    cap = b["caption_data"].caption
+    calls = {"fused": 0, "bwd": 0}
+    real_fused, real_bwd = ops.head_loss, ops.smooth_kl_bwd
+
+    def count_fused(*a, **k):
+        calls["fused"] += 1
+        return real_fused(*a, **k)
+
+    def count_bwd(*a, **k):
+        calls["bwd"] += 1
+        return real_bwd(*a, **k)
+    out = []
+    old = F.FUSED_HEAD_LOSS
+    ops.head_loss, ops.smooth_kl_bwd = count_fused, count_bwd
+    try:
+        for fused in (False, True):
+            F.FUSED_HEAD_LOSS = fused
+            calls["fused"] = calls["bwd"] = 0
+            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+            t.agent.train()
+            losses = [float(t.step(b["feature_stacks"], cap)) for _ in range(3)]
+            assert (calls["fused"], calls["bwd"]) == ((3, 0) if fused else (0, 3)), calls
+            out.append((losses, t.opt.flat.clone()))
+    finally:
+        F.FUSED_HEAD_LOSS = old
+        ops.head_loss, ops.smooth_kl_bwd = real_fused, real_bwd
+    (l0, p0), (l1, p1) = out
+    assert all(abs(a - c) < 2e-3 * abs(a) for a, c in zip(l0, l1)), (l0, l1)
+    assert float((p0 - p1).norm() / p0.norm()) < 3e-3
+
+
 def test_phased_adam_graph_equals_the_plain_graph(setup):
     """CaptionTrainer.phased_adam (one rank): backward in phases inside one graph, each bucket's Adam pass on a side stream as
     soon as its gradients are complete (FlatAdam.step_part) == the plain captured step."""
