@@ -521,16 +521,28 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
     return dw, db
 
 
-def _cast_dy(dy, rows, N, p_drop, seed, want_db):
+def _row_stride(t, cols):
+    """leading dimension of `t` read as (rows, cols) fp32 rows, or None when it is not such a matrix (a column slice of a
+    wider contiguous tensor -- d cat[x, goal] of the worker head -- is: no copy is needed to read it)"""
+    if t.dim() < 2 or t.shape[-1] != cols or t.stride(-1) != 1:
+        return None
+    for i in range(t.dim() - 2):
+        if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+            return None
+    return t.stride(-2) if t.stride(-2) >= cols else None
+
+
+def _cast_dy(dy, rows, N, p_drop, seed, want_db, ld=None):
     """bf16 copy of an incoming fp32 gradient (through the layer's output dropout) and, when the bias needs one, its
-    column sums from the same pass.  Returns (dyb, db or None)."""
+    column sums from the same pass.  Returns (dyb, db or None).  ld: row stride of dy (default N)."""
     dev = dy.device
+    ld = N if ld is None else ld
     dyb = SCRATCH.bf16(rows, N, dev)
     if want_db:
         db = SCRATCH.f32(N, device=dev)
-        ops.cast_colsum_bf16(dy, N, dyb, dyb.shape[1], rows, N, db, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+        ops.cast_colsum_bf16(dy, ld, dyb, dyb.shape[1], rows, N, db, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
         return dyb, db
-    ops.cast_bf16(dy, N, dyb, dyb.shape[1], rows, N, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
+    ops.cast_bf16(dy, ld, dyb, dyb.shape[1], rows, N, dropout_p=p_drop, seed=seed, seed_dev=SEEDS.dev)
     return dyb, None
 
 
@@ -624,10 +636,12 @@ class MHAFn(torch.autograd.Function):
         rows_q, rows_k = B * Sq, B * Sk
         ldx = pad8(dq)
         need = ctx.needs_input_grad
-        dy = dy.contiguous()
+        ld_dy = None if dy.is_contiguous() or (residual and has_ln) else _row_stride(dy, dq)
+        if ld_dy is None:
+            dy = dy.contiguous()             # (a strided row view is read where it lies: the cast below takes its row stride)
         keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         # d(out) through the residual-branch dropout -> bf16
-        dyb, dbo = _cast_dy(dy, rows_q, dq, p_drop, s_res, need[11])
+        dyb, dbo = _cast_dy(dy, rows_q, dq, p_drop, s_res, need[11], ld=ld_dy)
         # linear_d2Q backward; its dx is d(attention output), taken back through the output dropout in the epilogue
         dOb = torch.empty(rows_q, D, dtype=_BF16, device=dev)
         w_o = SHADOWS.weight(wo)
