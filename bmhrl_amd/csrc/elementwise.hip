@@ -613,6 +613,40 @@ __global__ void expand_goals_index_kernel(const int32_t* __restrict__ seg, int32
   const bool zero_tail = later && (any || b == 0);
   for (int j = prev; j < L; ++j) src[b * L + j] = zero_tail ? -1 : b * L + j;
 }
+// expand_goals_index + gather_rows as one launch (r03): block b rebuilds the row map of sample b from the labels (the
+// "a later row has a label" test is a parallel scan, the map itself one backward pass over the L positions in LDS) and
+// gathers its L rows; `src` is still written (the backward scatters along it).
+constexpr int EG_MAXL = 1024;
+__global__ __launch_bounds__(256) void expand_goals_kernel(const int32_t* __restrict__ seg, const float* __restrict__ x,
+                                                          int32_t* __restrict__ src, float* __restrict__ out,
+                                                          bf16_t* __restrict__ ob, long ldob, int B, int L, int D) {
+  __shared__ int s_src[EG_MAXL];
+  const int b = blockIdx.x;
+  int mine = 0, after = 0;
+  for (int i = threadIdx.x; i < L; i += 256) {
+    s_src[i] = seg[b * L + i];
+    mine |= s_src[i] != 0;
+  }
+  for (long i = (long)(b + 1) * L + threadIdx.x; i < (long)B * L; i += 256) after |= seg[i] != 0;
+  const int any = __syncthreads_or(mine), later = __syncthreads_or(after);
+  if (threadIdx.x == 0) {
+    const bool zero_tail = later && (any || b == 0);
+    int next = -1;
+    for (int l = L - 1; l >= 0; --l) {
+      if (s_src[l] != 0) next = l;
+      s_src[l] = next >= 0 ? b * L + next : (zero_tail ? -1 : b * L + l);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += 256) src[b * L + i] = s_src[i];
+  for (int i = threadIdx.x; i < L * D; i += 256) {
+    const int r = i / D, c = i - r * D;
+    const int s0 = s_src[r];
+    const float v = s0 >= 0 ? x[(long)s0 * D + c] : 0.f;
+    out[((long)b * L + r) * D + c] = v;
+    if (ob) ob[((long)b * L + r) * ldob + c] = (bf16_t)v;
+  }
+}
 __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ src, float* __restrict__ out,
                                    bf16_t* __restrict__ ob, long ldob, int D, long total) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1354,6 +1388,14 @@ extern "C" int bmhrl_gate_bwd(const float* dout, const float* cv, const float* c
 extern "C" int bmhrl_expand_goals_index(const int32_t* seg, int32_t* src, int32_t B, int32_t L, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(seg && src && B > 0 && L > 0);
   hipLaunchKernelGGL(expand_goals_index_kernel, dim3((B + 63) / 64), dim3(64), 0, S_(stream), seg, src, B, L);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_expand_goals(const int32_t* seg, const float* x, int32_t* src, float* out, void* out_bf16, int64_t ldob,
+                                  int32_t B, int32_t L, int32_t D, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(seg && x && src && out && B > 0 && L > 0 && L <= EG_MAXL && D > 0 && (!out_bf16 || ldob >= D));
+  hipLaunchKernelGGL(expand_goals_kernel, dim3((unsigned)B), dim3(256), 0, S_(stream), seg, x, src, out, (bf16_t*)out_bf16,
+                     (long)ldob, B, L, D);
   return hip_status(hipGetLastError());
 }
 

@@ -1549,10 +1549,13 @@ class ExpandGoalsFn(torch.autograd.Function):
         dev = goals.device
         seg2 = seg.reshape(B, L).to(torch.int32).contiguous()
         src = torch.empty(B * L, dtype=torch.int32, device=dev)
-        ops.expand_goals_index(seg2, src, B, L)
         out = torch.empty(B, L, D, device=dev)
         ob = SCRATCH.bf16(B * L, D, dev) if SCRATCH.armed else None        # (the goal attention's query operand: no cast launch)
-        ops.gather_rows(goals.contiguous(), src, out, ob, ob.shape[1] if ob is not None else 0, B * L, D)
+        if L <= 1024:
+            ops.expand_goals(seg2, goals.contiguous(), src, out, ob, ob.shape[1] if ob is not None else 0, B, L, D)
+        else:
+            ops.expand_goals_index(seg2, src, B, L)
+            ops.gather_rows(goals.contiguous(), src, out, ob, ob.shape[1] if ob is not None else 0, B * L, D)
         if ob is not None:
             SCRATCH.offer_bf16(out, B * L, D, ob)
         ctx.save_for_backward(src)

@@ -385,6 +385,13 @@ def expand_goals_index(seg, src, B, L):
     _lib.check(_lib.load().bmhrl_expand_goals_index(seg.data_ptr(), src.data_ptr(), B, L, stream()), "bmhrl_expand_goals_index")
 
 
+def expand_goals(seg, x, src, out, out_bf16, ldob, B, L, D):
+    """row map of Manager.expand_goals from the int32 labels `seg` (B, L) + the gather along it, one launch"""
+    _need_cuda(seg, x, src, out)
+    _lib.check(_lib.load().bmhrl_expand_goals(seg.data_ptr(), x.data_ptr(), src.data_ptr(), out.data_ptr(), _p(out_bf16), ldob,
+                                              B, L, D, stream()), "bmhrl_expand_goals")
+
+
 def gather_rows(x, src, out, out_bf16, ldob, rows, D):
     _lib.check(_lib.load().bmhrl_gather_rows(x.data_ptr(), src.data_ptr(), out.data_ptr(), _p(out_bf16), ldob, rows, D,
                                              stream()), "bmhrl_gather_rows")

@@ -312,6 +312,10 @@ int bmhrl_fusion_tail_bwd(const float* dout, const float* dout1, int64_t ldd0, i
  * bmhrl_expand_goals_index builds the (B*L) int32 source map from the segment labels with the reference's
  * row-transition quirks; fwd is a gather, bwd a scatter-add. */
 int bmhrl_expand_goals_index(const int32_t* seg, int32_t* src, int32_t B, int32_t L, bmhrl_stream_t stream);
+/* bmhrl_expand_goals_index + bmhrl_gather_rows as one launch (Manager.expand_goals, model/bm_hrl_agent.py:415-429): out[b, l] =
+ * x[src[b, l]] (0 where src = -1), `src` is written for the backward's scatter; out_bf16: optional bf16 copy.  L <= 1024. */
+int bmhrl_expand_goals(const int32_t* seg, const float* x, int32_t* src, float* out, void* out_bf16, int64_t ldob, int32_t B,
+                       int32_t L, int32_t D, bmhrl_stream_t stream);
 int bmhrl_gather_rows(const float* x, const int32_t* src, float* out, void* out_bf16, int64_t ldob, int64_t rows,
                       int32_t D, bmhrl_stream_t stream);
 int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, float* dx, int64_t rows, int32_t D,

@@ -456,6 +456,13 @@ def test_gate_expand_gather(dev, golden):
         out = torch.empty(B * L, 3, device=dev)
         ops.gather_rows(x.reshape(B * L, 3).to(dev), src, out, None, 0, B * L, 3)
         assert torch.equal(out.cpu().view(B, L, 3), expand_goals(x, seg))
+        # the one-launch form: same row map, same rows, bf16 copy in a padded buffer
+        src2 = torch.empty(B * L, dtype=torch.int32, device=dev)
+        out2 = torch.empty(B * L, 3, device=dev)
+        ob = torch.zeros(B * L, 8, dtype=torch.bfloat16, device=dev)
+        ops.expand_goals(seg.to(dev), x.reshape(B * L, 3).to(dev), src2, out2, ob, 8, B, L, 3)
+        assert torch.equal(src2, src) and torch.equal(out2, out)
+        assert torch.equal(ob[:, :3].float(), out.to(torch.bfloat16).float()) and float(ob[:, 3:].abs().max()) == 0.0
 
 
 def test_loss_kernels_vs_oracle(dev, golden):
