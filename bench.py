@@ -294,8 +294,6 @@ def main():
     trainer.agent.train()
     if rl:
         trainer.value_net.train()
-    else:
-        trainer.agent.set_inference_mode(True)
     fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
     cap = b["captions"].to(dev)
 

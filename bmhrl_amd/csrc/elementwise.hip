@@ -617,11 +617,52 @@ __global__ void expand_goals_index_kernel(const int32_t* __restrict__ seg, int32
 // "a later row has a label" test is a parallel scan, the map itself one backward pass over the L positions in LDS) and
 // gathers its L rows; `src` is still written (the backward scatters along it).
 constexpr int EG_MAXL = 1024;
+constexpr int EG_MAXD = 1024;
+// EXPLORE (Manager.forward with exploration on, model/bm_hrl_agent.py:444-452): before the segment copy the reference adds ONE
+// (D,) Gaussian vector to every token's goal: noise = normal(mean' , std') - 0.5 mean' with mean' = nanmean(x) / mean_factor,
+// std' = sqrt(nanmean(|x - nanmean(x)|^2)) / std_factor over ALL of x (detached), i.e. noise[c] = z_c std' + 0.5 mean'.  Every
+// block recomputes the two statistics over the whole (B L D) tensor itself -- 120 KB at the reference's sizes, served by L2 --
+// in the same order, so all blocks add the same vector without a second launch or a grid-wide hand-off; z_c comes from the
+// counter RNG of the dropout sites (seed + the device word a captured step advances), Box-Muller on two uniforms per column.
+__device__ __forceinline__ float goal_noise_z(uint64_t seed, int c) {
+  const float u1 = ((hash_u32(seed, 2ull * (uint64_t)c) >> 8) + 1u) * (1.0f / 16777216.0f);      // (0, 1]
+  const float u2 = (hash_u32(seed, 2ull * (uint64_t)c + 1ull) >> 8) * (1.0f / 16777216.0f);       // [0, 1)
+  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+template <bool EXPLORE>
 __global__ __launch_bounds__(256) void expand_goals_kernel(const int32_t* __restrict__ seg, const float* __restrict__ x,
                                                           int32_t* __restrict__ src, float* __restrict__ out,
-                                                          bf16_t* __restrict__ ob, long ldob, int B, int L, int D) {
+                                                          bf16_t* __restrict__ ob, long ldob, int B, int L, int D,
+                                                          float mean_factor, float std_factor, uint64_t seed,
+                                                          const uint64_t* __restrict__ seed_dev, float* __restrict__ noise_out) {
   __shared__ int s_src[EG_MAXL];
+  __shared__ float s_noise[EXPLORE ? EG_MAXD : 1];
+  __shared__ float red[16];
   const int b = blockIdx.x;
+  if constexpr (EXPLORE) {
+    const long total = (long)B * L * D;
+    float s = 0.f, cnt = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) {
+      const float v = x[i];
+      if (v == v) { s += v; cnt += 1.f; }
+    }
+    s = block_sum(s, red);
+    cnt = block_sum(cnt, red);                 // (exact below 2^24 elements per thread stride; the goals are B L 64)
+    const float mean = s / cnt;                // all-NaN input: NaN, as torch.nanmean
+    float sq = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) {
+      const float v = x[i];
+      if (v == v) sq += (v - mean) * (v - mean);
+    }
+    sq = block_sum(sq, red);
+    const float stdv = sqrtf(sq / cnt) / std_factor, m = mean / mean_factor;
+    const uint64_t sd = seed + (seed_dev ? seed_dev[0] : 0ull);
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float nz = goal_noise_z(sd, c) * stdv + 0.5f * m;
+      s_noise[c] = nz;
+      if (noise_out && b == 0) noise_out[c] = nz;
+    }
+  }
   int mine = 0, after = 0;
   for (int i = threadIdx.x; i < L; i += 256) {
     s_src[i] = seg[b * L + i];
@@ -642,7 +683,8 @@ __global__ __launch_bounds__(256) void expand_goals_kernel(const int32_t* __rest
   for (int i = threadIdx.x; i < L * D; i += 256) {
     const int r = i / D, c = i - r * D;
     const int s0 = s_src[r];
-    const float v = s0 >= 0 ? x[(long)s0 * D + c] : 0.f;
+    float v = s0 >= 0 ? x[(long)s0 * D + c] : 0.f;
+    if constexpr (EXPLORE) { if (s0 >= 0) v += s_noise[c]; }      // (the noise is added BEFORE the copy: zeroed tails stay zero)
     out[((long)b * L + r) * D + c] = v;
     if (ob) ob[((long)b * L + r) * ldob + c] = (bf16_t)v;
   }
@@ -1394,8 +1436,18 @@ extern "C" int bmhrl_expand_goals_index(const int32_t* seg, int32_t* src, int32_
 extern "C" int bmhrl_expand_goals(const int32_t* seg, const float* x, int32_t* src, float* out, void* out_bf16, int64_t ldob,
                                   int32_t B, int32_t L, int32_t D, bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(seg && x && src && out && B > 0 && L > 0 && L <= EG_MAXL && D > 0 && (!out_bf16 || ldob >= D));
-  hipLaunchKernelGGL(expand_goals_kernel, dim3((unsigned)B), dim3(256), 0, S_(stream), seg, x, src, out, (bf16_t*)out_bf16,
-                     (long)ldob, B, L, D);
+  hipLaunchKernelGGL(expand_goals_kernel<false>, dim3((unsigned)B), dim3(256), 0, S_(stream), seg, x, src, out,
+                     (bf16_t*)out_bf16, (long)ldob, B, L, D, 1.f, 1.f, 0ull, (const uint64_t*)nullptr, (float*)nullptr);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int bmhrl_expand_goals_explore(const int32_t* seg, const float* x, int32_t* src, float* out, void* out_bf16,
+                                          int64_t ldob, int32_t B, int32_t L, int32_t D, float mean_factor, float std_factor,
+                                          uint64_t seed, const uint64_t* seed_dev, float* noise_out, bmhrl_stream_t stream) {
+  BMHRL_CHECK_ARG(seg && x && src && out && B > 0 && L > 0 && L <= EG_MAXL && D > 0 && D <= EG_MAXD && (!out_bf16 || ldob >= D));
+  BMHRL_CHECK_ARG(mean_factor != 0.f && std_factor != 0.f && (int64_t)B * L * D < (1ll << 24));   // float element counts
+  hipLaunchKernelGGL(expand_goals_kernel<true>, dim3((unsigned)B), dim3(256), 0, S_(stream), seg, x, src, out,
+                     (bf16_t*)out_bf16, (long)ldob, B, L, D, mean_factor, std_factor, (uint64_t)seed, seed_dev, noise_out);
   return hip_status(hipGetLastError());
 }
 
@@ -1474,4 +1526,4 @@ extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 //     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce, bmhrl_fusion_tail_fwd / _bwd
 // 11: bmhrl_batch_head, bmhrl_smooth_kl_bwd loss_scale2, bmhrl_layernorm_fwd_groups / _bwd_groups, bmhrl_colsum_bf16_groups,
 //     bmhrl_cast_bf16_copies
-extern "C" int bmhrl_hip_abi_version(void) { return 12; }
+extern "C" int bmhrl_hip_abi_version(void) { return 13; }

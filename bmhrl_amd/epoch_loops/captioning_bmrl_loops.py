@@ -141,8 +141,7 @@ def warmstart_bmhrl_bl(cfg, models, scorer, loader, epoch, log_prefix, TBoard, *
     cap_model.train()
     loader.dataset.update_iterator()
     agent = _unwrap(cap_model)
-    agent.teach_warmstart()
-    agent.set_inference_mode(True)
+    agent.teach_warmstart()          # (exploration stays as it is -- on after the constructor --, reference :572-575)
     total, n = 0.0, 0
     for batch in loader:
         cap_optimizer.zero_grad()

@@ -1541,21 +1541,28 @@ class EmbedFn(torch.autograd.Function):
 
 
 class ExpandGoalsFn(torch.autograd.Function):
-    """Manager.expand_goals (model/bm_hrl_agent.py:415-429) as gather / scatter-add over a precomputed row map."""
+    """Manager.expand_goals (model/bm_hrl_agent.py:415-429) as gather / scatter-add over a precomputed row map.
+    explore = (mean_factor, std_factor) adds the manager's exploration vector (reference :444-452) in the same launch; the
+    noise is detached there, so the backward does not change.  noise_out: optional (D,) tensor that receives the vector."""
 
     @staticmethod
-    def forward(ctx, goals, seg):
+    def forward(ctx, goals, seg, explore=None, noise_out=None):
         B, L, D = goals.shape
         dev = goals.device
         seg2 = seg.reshape(B, L).to(torch.int32).contiguous()
         src = torch.empty(B * L, dtype=torch.int32, device=dev)
         out = torch.empty(B, L, D, device=dev)
         ob = SCRATCH.bf16(B * L, D, dev) if SCRATCH.armed else None        # (the goal attention's query operand: no cast launch)
-        if L <= 1024:
-            ops.expand_goals(seg2, goals.contiguous(), src, out, ob, ob.shape[1] if ob is not None else 0, B, L, D)
+        ldob = ob.shape[1] if ob is not None else 0
+        if explore is not None:
+            assert L <= 1024 and D <= 1024, "exploration noise: caption length and goal width up to 1024"
+            ops.expand_goals_explore(seg2, goals.contiguous(), src, out, ob, ldob, B, L, D, explore[0], explore[1], SEEDS.next(),
+                                     SEEDS.dev, noise_out)
+        elif L <= 1024:
+            ops.expand_goals(seg2, goals.contiguous(), src, out, ob, ldob, B, L, D)
         else:
             ops.expand_goals_index(seg2, src, B, L)
-            ops.gather_rows(goals.contiguous(), src, out, ob, ob.shape[1] if ob is not None else 0, B * L, D)
+            ops.gather_rows(goals.contiguous(), src, out, ob, ldob, B * L, D)
         if ob is not None:
             SCRATCH.offer_bf16(out, B * L, D, ob)
         ctx.save_for_backward(src)
@@ -1568,7 +1575,7 @@ class ExpandGoalsFn(torch.autograd.Function):
         (src,) = ctx.saved_tensors
         dx = SCRATCH.f32(B, L, D, device=dout.device)
         ops.scatter_add_rows(dout.contiguous(), src, dx, B * L, D)
-        return dx, None
+        return dx, None, None, None
 
 
 # WorkerHeadFn <-> TokenLossFn hand-over: addresses (+ version) of log-prob tensors a WorkerHeadFn produced, and the bf16

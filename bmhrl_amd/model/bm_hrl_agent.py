@@ -364,18 +364,18 @@ class Manager(nn.Module):
         self.d_goal = d_goal
         self.mean_factor = 10
         self.std_factor = 5
+        self.last_noise = None
 
     def forward(self, x, critic_mask):
         p = self.dout_p if self.training else 0.0
         g = LinearFn.apply(x, self.linear.weight, self.linear.bias, False, p)
         if self.exploration:
-            # one (d_goal,) Gaussian vector N(mean/10, std/5) - 0.5*mean/10 for all tokens (reference :444-452)
-            with torch.no_grad():
-                mean = torch.nanmean(g)
-                std = torch.sqrt(torch.nanmean((g - mean).abs() ** 2)) / self.std_factor
-                mean = mean / self.mean_factor
-                noise = torch.randn(self.d_goal, device=g.device) * std + mean - 0.5 * mean
-            g = g + noise
+            # one (d_goal,) Gaussian vector N(mean/10, std/5) - 0.5*mean/10 for all tokens (reference :444-452), drawn from the
+            # library's counter RNG inside the expand_goals launch (no torch generator: the captured step stays valid and
+            # the vector changes with every replay); last_noise keeps the vector of the latest call for inspection
+            if self.last_noise is None or self.last_noise.device != g.device:
+                self.last_noise = torch.zeros(self.d_goal, device=g.device)
+            return ExpandGoalsFn.apply(g, critic_mask, (float(self.mean_factor), float(self.std_factor)), self.last_noise)
         return ExpandGoalsFn.apply(g, critic_mask)
 
 

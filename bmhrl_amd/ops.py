@@ -392,6 +392,14 @@ def expand_goals(seg, x, src, out, out_bf16, ldob, B, L, D):
                                               B, L, D, stream()), "bmhrl_expand_goals")
 
 
+def expand_goals_explore(seg, x, src, out, out_bf16, ldob, B, L, D, mean_factor, std_factor, seed, seed_dev=None, noise_out=None):
+    """expand_goals with the manager's exploration vector (reference :444-452) added in the same launch"""
+    _need_cuda(seg, x, src, out)
+    _lib.check(_lib.load().bmhrl_expand_goals_explore(seg.data_ptr(), x.data_ptr(), src.data_ptr(), out.data_ptr(), _p(out_bf16),
+                                                      ldob, B, L, D, float(mean_factor), float(std_factor), int(seed),
+                                                      _p(seed_dev), _p(noise_out), stream()), "bmhrl_expand_goals_explore")
+
+
 def gather_rows(x, src, out, out_bf16, ldob, rows, D):
     _lib.check(_lib.load().bmhrl_gather_rows(x.data_ptr(), src.data_ptr(), out.data_ptr(), _p(out_bf16), ldob, rows, D,
                                              stream()), "bmhrl_gather_rows")

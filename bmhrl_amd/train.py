@@ -326,11 +326,14 @@ class CaptionTrainer:
 
     def __init__(self, cfg, voc_size: int, device, lr: float = 1e-4, weight_decay: float = 0.0, seed: int = 0,
                  critic_state: Optional[Dict[str, torch.Tensor]] = None, pad_idx: int = 1, smoothing: float = 0.7,
-                 phase: str = "warmstart", reward_fn=None, value_lr: float = 1e-4):
+                 phase: str = "warmstart", reward_fn=None, value_lr: float = 1e-4, exploration: Optional[bool] = None):
         """phase: "warmstart" (label-smoothing KL, reference :1132-1189), "worker" or "manager" (the RL step of
         train_bimodal_bl, reference :797-890: biased KL with sampled / arg-max tokens and their rewards + the value head's
         masked-MSE update; the phase decides which modules are trainable, teach_worker / teach_manager :572-589).
-        reward_fn(sampled (B, L), captions) -> (B, L) rewards (BASELINE configs[2]: synthetic)."""
+        reward_fn(sampled (B, L), captions) -> (B, L) rewards (BASELINE configs[2]: synthetic).
+        exploration: None = what the reference's phase leaves it at -- ON in the warmstart and manager phases (the constructor
+        sets it, teach_warmstart does not touch it: model/bm_hrl_agent.py:444-452,572-575), off in the worker phase;
+        False switches the manager's Gaussian goal vector off (comparisons with the CPU oracle, which cannot draw it)."""
         assert phase in ("warmstart", "worker", "manager")
         self.phase = phase
         self.reward_fn = reward_fn
@@ -350,7 +353,9 @@ class CaptionTrainer:
         elif phase == "manager":
             self.agent.teach_manager()          # manager fusion + manager trainable (exploration noise on, as the reference)
         else:
-            self.agent.set_inference_mode(True)     # manager.exploration off (warmstart)
+            self.agent.teach_warmstart()        # every module trainable; exploration stays as constructed (on), reference :572-575
+        if exploration is not None:
+            self.agent.manager.exploration = bool(exploration)
         self.value_net = None
         if phase != "warmstart":
             vcls = BMWorkerValueFunction if phase == "worker" else BMManagerValueFunction

@@ -316,6 +316,16 @@ int bmhrl_expand_goals_index(const int32_t* seg, int32_t* src, int32_t B, int32_
  * x[src[b, l]] (0 where src = -1), `src` is written for the backward's scatter; out_bf16: optional bf16 copy.  L <= 1024. */
 int bmhrl_expand_goals(const int32_t* seg, const float* x, int32_t* src, float* out, void* out_bf16, int64_t ldob, int32_t B,
                        int32_t L, int32_t D, bmhrl_stream_t stream);
+/* The same with the manager's exploration noise (Manager.forward, model/bm_hrl_agent.py:444-452; on after the constructor and
+ * left on by teach_warmstart / teach_manager, :572-589): ONE (D,) vector noise[c] = z_c * std' + 0.5 * mean', z ~ N(0, 1),
+ * mean' = nanmean(x) / mean_factor, std' = sqrt(nanmean(|x - nanmean(x)|^2)) / std_factor over all B*L*D entries of x, added
+ * to every goal before the segment copy (rows the copy zeroes stay zero).  z comes from the library's counter RNG over
+ * (seed + seed_dev[0], column): reproducible, and it changes between replays of a captured step.  noise_out: optional (D,)
+ * copy of the vector.  The noise is detached in the reference, so the backward is the plain scatter along `src`.
+ * B*L*D < 2^24, D <= 1024. */
+int bmhrl_expand_goals_explore(const int32_t* seg, const float* x, int32_t* src, float* out, void* out_bf16, int64_t ldob,
+                               int32_t B, int32_t L, int32_t D, float mean_factor, float std_factor, uint64_t seed,
+                               const uint64_t* seed_dev, float* noise_out, bmhrl_stream_t stream);
 int bmhrl_gather_rows(const float* x, const int32_t* src, float* out, void* out_bf16, int64_t ldob, int64_t rows,
                       int32_t D, bmhrl_stream_t stream);
 int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, float* dx, int64_t rows, int32_t D,

@@ -53,7 +53,7 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bmhrl_amd.train import CaptionTrainer
     dev = torch.device("cuda:0")
-    tr = CaptionTrainer(_cfg(), V, dev, seed=0)
+    tr = CaptionTrainer(_cfg(), V, dev, exploration=False, seed=0)
     assert tr._split()                               # more than one rank: phased backward + per-bucket all-reduce
     b = _batch([40 + rank], dev)
     loss = _run(tr, b)
@@ -77,7 +77,7 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
 
     from bmhrl_amd.train import CaptionTrainer
     dev = torch.device("cuda:0")
-    tr = CaptionTrainer(_cfg(), V, dev, seed=0)
+    tr = CaptionTrainer(_cfg(), V, dev, exploration=False, seed=0)
     tr.split_backward = False
     tr.opt.direct_grads = False          # this check reads the gathered bucket (one process normally leaves the gradients in place)
     b = _batch([40, 41], dev)
@@ -97,7 +97,7 @@ def _rl_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bmhrl_amd.train import CaptionTrainer
     dev = torch.device("cuda:0")
-    tr = CaptionTrainer(_cfg(), V, dev, seed=0, phase="worker", reward_fn=_reward)
+    tr = CaptionTrainer(_cfg(), V, dev, exploration=False, seed=0, phase="worker", reward_fn=_reward)
     assert tr._split()                               # the RL phases take the phased backward too
     b = _batch([40 + rank], dev)
     loss = _run(tr, b)
@@ -122,7 +122,7 @@ def test_two_ranks_worker_rl_phase_equal_one_process():
 
     from bmhrl_amd.train import CaptionTrainer
     dev = torch.device("cuda:0")
-    tr = CaptionTrainer(_cfg(), V, dev, seed=0, phase="worker", reward_fn=_reward)
+    tr = CaptionTrainer(_cfg(), V, dev, exploration=False, seed=0, phase="worker", reward_fn=_reward)
     tr.split_backward = False
     tr.opt.direct_grads = tr.vopt.direct_grads = False
     b = _batch([40, 41], dev)

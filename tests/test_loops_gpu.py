@@ -104,8 +104,8 @@ def test_trainer_graph_replay_matches_eager(setup):
     cfg, ds, loader, agent, wv, ls, bkl, dev = setup
     c2 = syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0)
     b = ds.batches[0]
-    t1 = CaptionTrainer(c2, 80, dev, lr=1e-3)
-    t2 = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+    t1 = CaptionTrainer(c2, 80, dev, exploration=False, lr=1e-3)
+    t2 = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-3)
     t1.agent.train(); t2.agent.train()
     cap = b["caption_data"].caption
     l_eager = [float(t1.step(b["feature_stacks"], cap)) for _ in range(4)]
@@ -135,7 +135,7 @@ def test_unzeroed_gradient_arena_is_only_ever_overwritten(setup):
     try:
         for poison in (False, True):
             F._ARENA_POISON = poison
-            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-3)
             t.agent.train()
             losses = [float(t.step(b["feature_stacks"], cap)) for _ in range(3)]
             assert t.scratch.need_raw > 100000 and t.scratch.raw is not None
@@ -175,7 +175,7 @@ def test_fused_head_loss_trains_like_the_four_kernel_tail(setup):
         for fused in (False, True):
             F.FUSED_HEAD_LOSS = fused
             calls["fused"] = calls["bwd"] = 0
-            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-3)
             t.agent.train()
             losses = [float(t.step(b["feature_stacks"], cap)) for _ in range(3)]
             assert (calls["fused"], calls["bwd"]) == ((3, 0) if fused else (0, 3)), calls
@@ -197,7 +197,7 @@ def test_phased_adam_graph_equals_the_plain_graph(setup):
     cap = b["caption_data"].caption
     out = []
     for phased in (False, True):
-        t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+        t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-3)
         t.agent.train()
         t.phased_adam = phased
         t.capture(b["feature_stacks"], cap, warmup=1)
@@ -218,7 +218,7 @@ def test_trainer_rl_graph_replay_matches_eager(setup):
     cap = b["caption_data"].caption
     rew = syn.synthetic_rewards(cap.shape[0], cap.shape[1] - 1, seed=5).to(dev)
     fn = lambda sampled, captions: rew
-    mk = lambda: CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3, phase="worker",
+    mk = lambda: CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-3, phase="worker",
                                 reward_fn=fn, value_lr=1e-3)
     t1 = mk()
     t1.agent.train(); t1.value_net.train()
@@ -273,7 +273,7 @@ def test_adam_pass_keeps_weight_shadows_current(setup):
     for fused in (True, False):
         FlatAdam.fused_shadows = fused
         try:
-            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-3)
+            t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-3)
             t.agent.train()
             losses[fused] = [float(t.step(b["feature_stacks"], cap)) for _ in range(3)]
             if fused:
@@ -319,7 +319,7 @@ def test_shadows_made_after_capture_follow_the_replayed_updates(setup):
     cfg, ds, loader, agent, wv, ls, bkl, dev = setup
     b = ds.batches[0]
     cap = b["caption_data"].caption
-    t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, lr=1e-2)
+    t = CaptionTrainer(syn.tiny_cfg(d_model=1024, rl_att_heads=4, dout_p=0.0), 80, dev, exploration=False, lr=1e-2)
     t.agent.train()
     t.capture(b["feature_stacks"], cap, warmup=1)
     att = t.agent.bm_worker_fus.decoder.layers[0].self_att

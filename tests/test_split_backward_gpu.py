@@ -18,7 +18,7 @@ def test_split_backward_equals_single_phase():
     cap = b["captions"].to(dev)
     runs = []
     for split in (False, False, True):
-        t = CaptionTrainer(syn.default_cfg(dout_p=0.0), 300, dev, lr=1e-3)
+        t = CaptionTrainer(syn.default_cfg(dout_p=0.0), 300, dev, exploration=False, lr=1e-3)
         t.agent.train()
         t.split_backward = split
         init = t.opt.flat.clone()
@@ -58,7 +58,7 @@ dev = torch.device("cuda:0")
 b = syn.synthetic_batch(2, 128, 200, 12, 300, seed=2)
 fs = {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}
 cap = b["captions"].to(dev)
-t = CaptionTrainer(syn.default_cfg(dout_p=0.1), 300, dev, lr=1e-3)
+t = CaptionTrainer(syn.default_cfg(dout_p=0.1), 300, dev, exploration=False, lr=1e-3)
 t.agent.train()
 t.split_backward = sys.argv[2] == "split"
 t.capture(fs, cap, warmup=1)
