@@ -7,9 +7,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbmhrl_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "attention128.hip", "attention_f16.hip", "attention128_f16.hip", "small_attention.hip",
+SOURCES = ["gemm.hip", "attention.hip", "attention128.hip", "attention128p.hip", "attention_f16.hip", "attention128_f16.hip", "small_attention.hip",
            "memory_attention.hip", "elementwise.hip", "loss.hip", "critic.hip"]
-HEADERS = ["common.h", "attention_fwd.h", "attention_bwd.h"]
+HEADERS = ["common.h", "attention_fwd.h", "attention_bwd.h", "attention_pair.h"]
 # attention.hip: the eight 16-register O^T accumulators are loop-carried vector PHIs; AMDGPUCodeGenPrepare would break
 # them into 128 scalar (VGPR) PHIs, i.e. 128 accumulator<->VGPR copies per key tile around the MFMAs.
 # gemm.hip: same for the MFMA tile accumulators of the main loop (1-3 % on the large shapes).
@@ -17,6 +17,7 @@ _VECTOR_PHIS = ["-mllvm", "-amdgpu-codegenprepare-break-large-phis=false"]
 # attention128.hip (256 registers per wave, two waves per SIMD): MFMA results in arch VGPRs -- with no accumulator-register
 # operand in the file the compiler treats the 256 registers as one file (see the file's header).
 EXTRA_FLAGS = {"attention.hip": _VECTOR_PHIS, "gemm.hip": _VECTOR_PHIS, "attention_f16.hip": _VECTOR_PHIS,
+               "attention128p.hip": _VECTOR_PHIS,
                "attention128.hip": _VECTOR_PHIS + ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "attention128_f16.hip": _VECTOR_PHIS + ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 

@@ -6,6 +6,12 @@
 // v_accvgpr_read per score) and O^T needs no copies around its MFMAs.
 #include "attention_bwd.h"
 
+// attention128p.hip
+bool bmhrl_attn128_pair_ok(int B, int H, int Sq, int Sk);
+int bmhrl_attn128_pair_fwd(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo, float* row_max,
+                           float* row_sum, const uint8_t* mask, int64_t mask_sb, int32_t B, int32_t H, int32_t Sq, int32_t Sk,
+                           float scale, hipStream_t stream);
+
 namespace {
 int g_cfg128 = 0;   // (QW, KW) split: 0 = automatic
 }  // namespace
@@ -17,7 +23,7 @@ extern "C" int bmhrl_attention_shared128_fwd(const void* Qp, int64_t ldq, const 
                                              int32_t B, int32_t H, int32_t Sq, int32_t Sk, float scale,
                                              bmhrl_stream_t stream) {
   return attention128_entry(Qp, ldq, X, ldx, ctx, ldo, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, g_cfg128,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, bmhrl_attn128_pair_fwd, bmhrl_attn128_pair_ok);
 }
 
 extern "C" int64_t bmhrl_attention_shared128_bwd_workspace(int32_t B, int32_t H, int32_t Sk) {

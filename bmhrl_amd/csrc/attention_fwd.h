@@ -992,8 +992,9 @@ __global__ __launch_bounds__(64 * QW * KW, DK == 128 ? 2 : 1) void attn_fwd_kern
 }
 
 const int g_attn_dbg = getenv("BMHRL_ATTN_DBG") ? atoi(getenv("BMHRL_ATTN_DBG")) : 0;   // read once, at load time
+const bool g_attn_pair_on = getenv("BMHRL_ATTN_PAIR") && atoi(getenv("BMHRL_ATTN_PAIR")) != 0;    // the pair form in the automatic choice
 
-inline void attn_trace_dump(const char* what, int Sq, int Sk, hipStream_t stream) {
+inline void attn_trace_dump(const char* what, int Sq, int Sk, hipStream_t stream, int last = 10, int total_at = 10) {
 #ifdef BMHRL_ATTN_TRACE
   if (getenv("BMHRL_ATTN_TRACE")) {
     long long hh[2][16];
@@ -1001,12 +1002,12 @@ inline void attn_trace_dump(const char* what, int Sq, int Sk, hipStream_t stream
     (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_attn_trace), sizeof(hh));
     for (int w = 0; w < 2; ++w) {
       fprintf(stderr, "%s trace (%s block, Sq %d Sk %d):", what, w ? "last" : "first", Sq, Sk);
-      for (int i = 1; i <= 10; ++i) fprintf(stderr, " %lld", hh[w][i] - hh[w][i - 1]);
-      fprintf(stderr, "  total %lld\n", hh[w][10] - hh[w][0]);
+      for (int i = 1; i <= last; ++i) fprintf(stderr, " %lld", hh[w][i] - hh[w][i - 1]);
+      fprintf(stderr, "  total %lld\n", hh[w][total_at] - hh[w][0]);
     }
   }
 #else
-  (void)what; (void)Sq; (void)Sk; (void)stream;
+  (void)what; (void)Sq; (void)Sk; (void)stream; (void)last; (void)total_at;
 #endif
 }
 
@@ -1063,10 +1064,16 @@ int attention256_entry(const void* Q, int64_t ldq, const void* K, int64_t ldk, c
   return hip_status(e);
 }
 
+// attention128p.hip (the pair form, bf16 operands only): code 14; nullptr in translation units that do not link it
+typedef int (*attn128_pair_fn)(const void*, int64_t, const void*, int64_t, void*, int64_t, float*, float*, const uint8_t*, int64_t,
+                               int32_t, int32_t, int32_t, int32_t, float, hipStream_t);
+typedef bool (*attn128_pair_ok_fn)(int, int, int, int);
+
 template <int UNUSED = 0>
 int attention128_entry(const void* Qp, int64_t ldq, const void* X, int64_t ldx, void* ctx, int64_t ldo, float* row_max,
                               float* row_sum, const uint8_t* mask, int64_t mask_sb, int32_t B, int32_t H, int32_t Sq,
-                              int32_t Sk, float scale, int code, hipStream_t stream) {
+                              int32_t Sk, float scale, int code, hipStream_t stream, attn128_pair_fn pair_fn = nullptr,
+                              attn128_pair_ok_fn pair_ok = nullptr) {
   constexpr int DK = 128;
   BMHRL_CHECK_ARG(Qp && X && ctx && row_max && row_sum);
   BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0);
@@ -1085,9 +1092,16 @@ int attention128_entry(const void* Qp, int64_t ldq, const void* X, int64_t ldx, 
   // SIMD two waves that way; else 2 x 2 (64 rows, two key halves).  Both request the K fragments of the next tile across
   // the barrier (four stages of the shared image).  Measured on MI355X at B16 H4 (tests/kbench/attn_bench time):
   // Sq800 Sk800 30.4 vs 34.9 us, Sq256 Sk800 20.2 vs 14.3 us; eight waves (2 x 4) lose to 2 x 2 on every shape tried.
+  // The pair form (attention_pair.h: 64 slots x 4 key splits per workgroup, no barrier in the loop) when its workgroups fill
+  // the chip in one round and a key split has at least two tiles -- the shape of BASELINE configs[1]'s V<-A attention.
   if (code == 0) {
     const int64_t rows32 = (int64_t)B * H * ((Sq + 31) / 32);      // 32-row query blocks
-    code = rows32 >= 1536 ? 41 : 22;
+    const bool pair = pair_fn != nullptr && pair_ok(B, H, Sq, Sk) && rows32 <= 2 * 304 && Sk >= 256 && g_attn_pair_on;
+    code = pair ? 14 : (rows32 >= 1536 ? 41 : 22);
+  }
+  if (code == 14) {
+    if (pair_fn == nullptr || !pair_ok(B, H, Sq, Sk)) return -22;
+    return pair_fn(Qp, ldq, X, ldx, ctx, ldo, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, stream);
   }
   hipError_t e;
   if (code == 41) e = launch_attn<DK, 4, 1, 4, true, true>(a, stream);

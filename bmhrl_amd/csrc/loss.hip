@@ -343,13 +343,33 @@ __global__ __launch_bounds__(256) void head_loss_kernel(float* __restrict__ x, l
   // cost 16 us): the rows are added as 2^-32 fixed point with a 64-bit integer atomic -- associative, so the sum does not
   // depend on the order the blocks arrive in -- and the block whose counter increment comes last reads the total.  An
   // atomic that has RETURNED has been performed where all XCDs see it, so a block's increment follows its own addition.
+  // A row loss that is not finite (a NaN / Inf logit: training has diverged) has no fixed-point image -- the conversion of a
+  // NaN or an out-of-range double to an integer is undefined and would leave a finite garbage sum -- so it is reported through
+  // the fourth sync word instead (bit 0 NaN, bit 1 +Inf or beyond the fixed-point range, bit 2 -Inf ...), which the last block
+  // turns into what the sum of the float rows would have been: the loss the caller monitors shows the divergence.
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(sync);
+  constexpr float FIXED_MAX = 1048576.f;                       // 2^20 per row: 2^52 in fixed point, room for 2^11 such rows
+  unsigned bad = 0u;
+  if (loss != loss) bad = 1u;
+  else if (loss > FIXED_MAX) bad = 2u;
+  else if (loss < -FIXED_MAX) bad = 4u;
+  if (bad) {
+    const unsigned f0 = atomicOr(sync + 3, bad);               // (returned: performed before this block's arrival below)
+    asm volatile("" : : "v"(f0) : "memory");
+    loss = 0.f;
+  }
   const long long fixed = (long long)((double)loss * 4294967296.0);
   const unsigned long long before = atomicAdd(acc, (unsigned long long)fixed);
   asm volatile("" : : "v"((unsigned)before) : "memory");
   if (atomicAdd(sync + 2, 1u) != (unsigned)(rows - 1)) return;
   const long long total = (long long)atomicAdd(acc, 0ull);
-  out[0] = (float)((double)total * (1.0 / 4294967296.0)) * w;
+  const unsigned flags = atomicExch(sync + 3, 0u);
+  float sum = (float)((double)total * (1.0 / 4294967296.0));
+  if (flags & 1u) sum = NAN;
+  else if ((flags & 6u) == 6u) sum = NAN;                      // +Inf + -Inf
+  else if (flags & 2u) sum = INFINITY;
+  else if (flags & 4u) sum = -INFINITY;
+  out[0] = sum * w;
   out[1] = w;
   atomicExch(acc, 0ull);
   atomicExch(sync + 2, 0u);

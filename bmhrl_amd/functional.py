@@ -8,6 +8,7 @@ vocabulary logits and all reductions are fp32; GEMM and attention operands are b
 from __future__ import annotations
 
 import math
+import itertools
 import os
 import weakref
 from typing import Optional
@@ -197,6 +198,7 @@ class ScratchState:
         self.raw: Optional[torch.Tensor] = None       # never zeroed: outputs their producer writes whole (f32(zero=False))
         self.need_raw = 0
         self.pool = {}
+        self.sync = None                               # the four sync words of ops.head_loss (re-armed by the kernel itself)
 
 
 class StepScratch:
@@ -259,6 +261,20 @@ class StepScratch:
         self.cursor = {}
         self.memo = {}
         self.armed = True
+
+    def sync_words(self, device) -> torch.Tensor:
+        """four zeroed int32 words for ops.head_loss (64-bit row sum, arrival count, non-finite flags).  Inside a step they belong
+        to the bound ScratchState -- two trainers (or two captured graphs replaying on different streams) never share the
+        accumulator --; outside a step one set per device."""
+        if self.armed:
+            st = self.state
+            if st.sync is None or st.sync.device != device:
+                st.sync = torch.zeros(4, dtype=torch.int32, device=device)
+            return st.sync
+        c = _HEAD_LOSS_COUNTER.get(device)
+        if c is None:
+            c = _HEAD_LOSS_COUNTER[device] = torch.zeros(4, dtype=torch.int32, device=device)
+        return c
 
     def off_of_last_step(self) -> int:
         """elements of the bound state's arena a step may have written (its own high-water mark)"""
@@ -1578,16 +1594,44 @@ class ExpandGoalsFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-# WorkerHeadFn <-> TokenLossFn hand-over: addresses (+ version) of log-prob tensors a WorkerHeadFn produced, and the bf16
-# d logits a TokenLossFn(sole_consumer=True) computed in place of the fp32 d log-probs it returns (keyed by that tensor)
-_HEAD_LOGP = {}
-_GRAD_TWIN = {}
+# WorkerHeadFn <-> TokenLossFn hand-over.  Nothing is keyed on a raw address: a head registers the log-prob TENSOR it returned
+# (weak reference + version + a token it keeps in its ctx); a TokenLossFn(sole_consumer=True) that is given that very tensor
+# object takes the token, and in backward leaves the bf16 d logits its gradient kernel wrote under the token.  The gradient it
+# RETURNS for the log-probs is a zero-stride view of one NaN (no memory, no launch): the head's backward checks that exactly
+# that placeholder arrives -- a second consumer of the log-probs, a tensor hook or anything else that changes the gradient on
+# its way raises there, and whatever reads the placeholder elsewhere (retain_grad) sees NaN, never uninitialised memory.
+_HEAD_LOGP = {}          # id(logp) -> (weakref(logp), version, shape, token)
+_GRAD_TWIN = {}          # token -> bf16 d logits
+_HEAD_TOKENS = itertools.count(1)
+_NAN_SCALAR = {}         # device -> 0-d NaN tensor (the placeholder gradient is an expand() of it)
 # The warmstart trainer announces its loss before the agent's forward (request_head_loss): the worker head then runs the
 # log-softmax, the label-smoothing row sums, the token-normalised loss and d logits as ONE launch (ops.head_loss) and
-# TokenLossFn, finding the result under the log-probs' address, launches nothing -- forward or backward.
+# TokenLossFn, finding the result under the head's token, launches nothing -- forward or backward.
 _HEAD_LOSS_REQ = []
-_HEAD_LOSS_OUT = {}
-_HEAD_LOSS_COUNTER = {}
+_HEAD_LOSS_OUT = {}      # token -> (request, flat targets, [loss, scale], bf16 d logits)
+_HEAD_LOSS_COUNTER = {}  # device -> the kernel's four sync words when no trainer's ScratchState is bound (unit tests)
+
+
+def _nan_placeholder(shape, device):
+    n = _NAN_SCALAR.get(device)
+    if n is None:
+        n = _NAN_SCALAR[device] = torch.full((), float("nan"), device=device)
+    return n.expand(*shape)
+
+
+def _is_placeholder(t: torch.Tensor) -> bool:
+    n = _NAN_SCALAR.get(t.device)
+    return n is not None and t.data_ptr() == n.data_ptr() and all(st == 0 for st in t.stride()) and n._version == 0
+
+
+def _head_token_of(logp: torch.Tensor):
+    """token of the WorkerHeadFn that returned exactly this tensor object, unchanged since; None otherwise"""
+    e = _HEAD_LOGP.get(id(logp))
+    if e is None or e[0]() is not logp or e[1] != logp._version or e[2] != tuple(logp.shape):
+        return None
+    return e[3]
+
+
 FUSED_HEAD_LOSS = os.environ.get("BMHRL_FUSED_HEAD_LOSS", "1") == "1"
 
 
@@ -1624,24 +1668,24 @@ class WorkerHeadFn(torch.autograd.Function):
         ops.gemm(xb, wb, rows, V, ld, lda=ld, ldb=ld, C_f32=logp, ldc=V, bias=b.detach())
         req = _HEAD_LOSS_REQ.pop() if _HEAD_LOSS_REQ else None
         _HEAD_LOSS_OUT.clear()
+        token = next(_HEAD_TOKENS)
         gb = SCRATCH.bf16(rows, V, dev) if req is not None else None
         if gb is not None and req[0].numel() == rows and ops.head_loss_ok(V, V, gb.shape[1]):
             trg, smoothing, pad_idx, factor, weight, dloss = req
-            counter = _HEAD_LOSS_COUNTER.get(dev)
-            if counter is None:
-                counter = _HEAD_LOSS_COUNTER[dev] = torch.zeros(4, dtype=torch.int32, device=dev)   # 64-bit sum, arrival count
+            counter = SCRATCH.sync_words(dev)                # 64-bit sum, arrival count, non-finite flags: the bound trainer's own
             trg = trg.contiguous().view(-1)
             row_loss = torch.empty(rows, device=dev)
             out = torch.empty(2, device=dev)                 # [loss, scale]
             ops.head_loss(logp, V, trg, smoothing, pad_idx, weight, factor, dloss, row_loss, out, gb, gb.shape[1], counter, rows, V)
-            _HEAD_LOSS_OUT[logp.data_ptr()] = (req, trg, out, gb)
+            _HEAD_LOSS_OUT[token] = (req, trg, out, gb)
         else:
             ops.log_softmax_(logp, V, rows, V)
         ctx.save_for_backward(xb, w, logp)
         ctx.cfg = (B, L, d1, d2, V)
-        if len(_HEAD_LOGP) > 64:
-            _HEAD_LOGP.clear()
-        _HEAD_LOGP[logp.data_ptr()] = (logp._version, tuple(logp.shape))
+        ctx.token = token
+        for k in [k for k, e in _HEAD_LOGP.items() if e[0]() is None]:      # (entries of tensors that are gone)
+            del _HEAD_LOGP[k]
+        _HEAD_LOGP[id(logp)] = (weakref.ref(logp), logp._version, tuple(logp.shape), token)
         return logp
 
     @staticmethod
@@ -1651,9 +1695,14 @@ class WorkerHeadFn(torch.autograd.Function):
         dev = dlogp.device
         rows, K = B * L, d1 + d2
         need = ctx.needs_input_grad
-        _HEAD_LOGP.pop(logp.data_ptr(), None)
-        gb = _GRAD_TWIN.pop(dlogp.data_ptr(), None)       # TokenLossFn(sole_consumer=True): d logits, already bf16
+        gb = _GRAD_TWIN.pop(ctx.token, None)              # TokenLossFn(sole_consumer=True): d logits, already bf16
         _GRAD_TWIN.clear()
+        if gb is not None and not _is_placeholder(dlogp):
+            raise RuntimeError("TokenLossFn(sole_consumer=True) handed its d logits to the worker head, but the gradient that "
+                               "reached the head is not that node's placeholder: the log-probabilities have a second consumer, "
+                               "a tensor hook or a retained gradient. Pass sole_consumer=False.")
+        if gb is None and _is_placeholder(dlogp):
+            raise RuntimeError("the worker head received TokenLossFn's placeholder gradient without the d logits that go with it")
         if gb is None:
             gb = SCRATCH.bf16(rows, V, dev)
             ops.log_softmax_bwd(dlogp.contiguous(), logp, V, gb, gb.shape[1], rows, V)
@@ -1729,6 +1778,60 @@ class SmoothKLFn(torch.autograd.Function):
         return g.view(B, S, V), None, None, None, None, None, None
 
 
+class GivenAmpKLFn(torch.autograd.Function):
+    """BiasedKL.forward of the reference as its signature reads (loss/biased_kl.py:22-53): the amplitude `biased_offset` is an
+    ordinary tensor ARGUMENT.  Whether the divergence's gradient reaches the prediction through it is autograd's business -- an
+    amplitude computed from the prediction (the loops' clamp(score * p(a) * n, 0, 1)) carries it, a detached one does not --, so
+    this node differentiates w.r.t. both inputs: d rows / d log-probs with the amplitude held fixed, and d rows / d amplitude.
+    Same kernels as SmoothKLFn (which forms the amplitude itself and therefore always includes the path through p(a)): the
+    given amplitude is reproduced as score' * p(a) with score' = amp / p(a); bmhrl_smooth_kl_amp_grad gives the share e of the
+    gradient that SmoothKLFn's backward sends through the row's own token, which is taken out of d log-probs again and,
+    divided by the amplitude, is d rows / d amp.  Amplitudes are expected in [0, 1] (every caller clamps them)."""
+
+    @staticmethod
+    def forward(ctx, logp, trg, biased_trg, amp, smoothing, pad_idx):
+        B, S, V = logp.shape
+        rows = B * S
+        dev = logp.device
+        logp = logp.contiguous()
+        trg = trg.contiguous().view(-1)
+        bt = biased_trg.contiguous().view(-1)
+        a = amp.detach().float().contiguous().view(-1)
+        p = torch.gather(logp.view(rows, V), 1, bt.view(rows, 1)).squeeze(1).exp().clamp_min(1e-30)
+        one = torch.ones_like(a)
+        row_loss = torch.empty(rows, device=dev)
+        ops.smooth_kl_fwd(logp, V, trg, bt, (a / p).contiguous(), one, smoothing, pad_idx, -1, row_loss, None, rows, V)
+        ctx.save_for_backward(logp, trg, bt, a, p)
+        ctx.cfg = (B, S, V, smoothing, pad_idx, tuple(amp.shape))
+        return row_loss
+
+    @staticmethod
+    def backward(ctx, drow):
+        B, S, V, smoothing, pad_idx, amp_shape = ctx.cfg
+        logp, trg, bt, a, p = ctx.saved_tensors
+        rows = B * S
+        dev = logp.device
+        one = torch.ones(rows, device=dev)
+        drow = drow.contiguous().view(rows)
+        g_logp = g_amp = None
+        sc = (a / p).contiguous()
+        if ctx.needs_input_grad[0]:
+            g = torch.empty(rows, V, device=dev)
+            ops.smooth_kl_bwd(logp, V, trg, bt, sc, one, smoothing, pad_idx, -1, one[:1], None, 0, g, rows, V, wrt_logits=False)
+            e = torch.empty(rows, device=dev)
+            ops.smooth_kl_amp_grad(logp, V, trg, bt, sc, one, smoothing, pad_idx, -1, e, rows, V)
+            g.scatter_add_(1, bt.view(rows, 1), (-e).view(rows, 1))        # the amplitude is an input here, not a function of p(a)
+            g_logp = (g * drow.view(rows, 1)).view(B, S, V)
+        if ctx.needs_input_grad[3]:
+            # d rows / d amp = e / amp; evaluated at >= 1e-6 so that an amplitude of exactly 0 has its (finite) slope
+            # (and at most 1 - 1e-6: (amp / p) * p may round to just above 1, which the kernel reads as a clamped amplitude)
+            ac = a.clamp(1e-6, 1.0 - 1e-6)
+            e = torch.empty(rows, device=dev)
+            ops.smooth_kl_amp_grad(logp, V, trg, bt, (ac / p).contiguous(), one, smoothing, pad_idx, -1, e, rows, V)
+            g_amp = (e / ac * drow).view(amp_shape)
+        return g_logp, None, None, g_amp, None, None
+
+
 class TokenLossFn(torch.autograd.Function):
     """weight * sum(LabelSmoothing / BiasedKL rows) / (n_tokens * factor) as ONE autograd node -- the reduction the loops
     write as `torch.sum(criterion(pred, y)) / n_tokens` (epoch_loops/captioning_bmrl_loops.py:1156-1158; `/ (n_tokens *
@@ -1743,9 +1846,11 @@ class TokenLossFn(torch.autograd.Function):
         B, S, V = logp.shape
         rows = B * S
         dev = logp.device
-        ctx.twin = bool(sole_consumer) and logp.is_contiguous() and _HEAD_LOGP.get(logp.data_ptr()) == (logp._version, tuple(logp.shape))
+        token = _head_token_of(logp) if (sole_consumer and logp.is_contiguous()) else None
+        ctx.twin = token is not None
+        ctx.token = token
         ctx.fused = None
-        done = _HEAD_LOSS_OUT.pop(logp.data_ptr(), None) if ctx.twin and biased_trg is None else None
+        done = _HEAD_LOSS_OUT.pop(token, None) if ctx.twin and biased_trg is None else None
         _HEAD_LOSS_OUT.clear()
         if done is not None:
             (r_trg, r_s, r_pad, r_f, r_w, r_dl), trg_flat, out, gb = done
@@ -1778,19 +1883,20 @@ class TokenLossFn(torch.autograd.Function):
         B, S, V, smoothing, pad_idx = ctx.cfg
         logp, trg, bt, sc, nr, out = ctx.saved_tensors
         rows = B * S
-        g = torch.empty(rows, V, device=logp.device)
         dl = dloss.reshape(1)                                # (one element; multiplied in by the kernel)
-        if ctx.fused is not None and ctx.fused[1] == dloss.data_ptr():
-            _GRAD_TWIN[g.data_ptr()] = ctx.fused[0]          # d logits were final in the forward
-        elif ctx.twin:
-            # g stays unwritten: WorkerHeadFn.backward finds the bf16 d logits under g's address
-            gb = ctx.fused[0] if ctx.fused is not None else SCRATCH.bf16(rows, V, logp.device)
-            ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], gb, gb.shape[1], None, rows, V,
-                              wrt_logits=True, loss_scale2=dl)
-            _GRAD_TWIN[g.data_ptr()] = gb
-        else:
-            ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], None, 0, g, rows, V, wrt_logits=False,
-                              loss_scale2=dl)
+        if ctx.twin:
+            # the head's backward finds the bf16 d logits under its token; what travels through autograd is a NaN placeholder
+            if ctx.fused is not None and ctx.fused[1] == dloss.data_ptr():
+                gb = ctx.fused[0]                            # d logits were final in the forward
+            else:
+                gb = ctx.fused[0] if ctx.fused is not None else SCRATCH.bf16(rows, V, logp.device)
+                ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], gb, gb.shape[1], None, rows, V,
+                                  wrt_logits=True, loss_scale2=dl)
+            _GRAD_TWIN[ctx.token] = gb
+            return _nan_placeholder((B, S, V), logp.device), None, None, None, None, None, None, None, None, None
+        g = torch.empty(rows, V, device=logp.device)
+        ops.smooth_kl_bwd(logp, V, trg, bt, sc, nr, smoothing, pad_idx, -1, out[1:2], None, 0, g, rows, V, wrt_logits=False,
+                          loss_scale2=dl)
         return g.view(B, S, V), None, None, None, None, None, None, None, None, None
 
 

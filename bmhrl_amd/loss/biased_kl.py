@@ -1,14 +1,17 @@
 """BiasedKL and Reinforce with the reference's signatures (loss/biased_kl.py:11-53, :61-81).
 
-BiasedKL.forward(pred, trg, biased_trg, biased_offset) of the reference receives the amplitude as a tensor that is
-still attached to `pred` (epoch_loops/captioning_bmrl_loops.py:285,321-322).  The fused kernel computes the
-amplitude itself from (score, tokens per row), so the worker step calls `biased_kl_from_score`; the 4-argument
-reference form is kept for an amplitude that is a plain (detached) tensor."""
+BiasedKL.forward(pred, trg, biased_trg, biased_offset) takes the amplitude as a tensor ARGUMENT, exactly as the reference
+does: if the caller computed it from `pred` (epoch_loops/captioning_bmrl_loops.py:285,321-322 leave it attached) the
+gradient flows through it, if the caller detached it, it does not -- functional.GivenAmpKLFn differentiates w.r.t. both.
+The trainer's own steps use the fused forms (`biased_kl_from_score`, `biased_kl_from_segments`), whose kernels form the
+amplitude clamp(score * p(a) * n, 0, 1) themselves: same values and gradients as the attached 4-argument call, fewer passes.
+forward() returns the ROW SUMS (B*S, 1) of the divergence (the callers only ever sum it); `unreduced()` gives the (B*S, V)
+tensor itself."""
 import torch
 import torch.nn as nn
 
 from .. import ops
-from ..functional import ManagerKLFn, SmoothKLFn
+from ..functional import GivenAmpKLFn, ManagerKLFn, SmoothKLFn
 
 
 class BiasedKL(nn.Module):
@@ -43,14 +46,9 @@ class BiasedKL(nn.Module):
         return out
 
     def forward(self, pred, trg, biased_trg, biased_offset, segments=None):
-        # amp = clamp(offset * p(a) * n, 0, 1) with offset' = offset / p(a), n = 1 reproduces a given amplitude;
-        # the gradient then treats the amplitude as constant only if it saturates -- use biased_kl_from_score
-        # for the attached form.
-        B, S, V = pred.shape
-        with torch.no_grad():
-            p = torch.gather(torch.exp(pred), 2, biased_trg.unsqueeze(-1)).squeeze(-1)
-            score = biased_offset.detach().float() / p.clamp_min(1e-30)
-        return self.biased_kl_from_score(pred, trg, biased_trg, score, torch.ones_like(score))[0]
+        """reference :22-53 (`segments` is ignored there too); amplitudes in [0, 1]"""
+        rows = GivenAmpKLFn.apply(pred, trg, biased_trg, biased_offset, float(self.ls), int(self.pad_idx))
+        return rows.unsqueeze(-1)
 
 
 class Reinforce(nn.Module):

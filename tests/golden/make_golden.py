@@ -134,6 +134,41 @@ def losses_random():
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
 
 
+def biased_kl_forward_cases():
+    """BiasedKL.forward (loss/biased_kl.py:22-53) as its callers may use it: the amplitude `biased_offset` is an ordinary
+    tensor argument -- attached to the prediction (the loops' clamp(score * p(a) * n, 0, 1), :285,321-322), detached, or
+    attached through some other function of the prediction.  Divergence and the gradient w.r.t. the logits for all three."""
+    from loss.biased_kl import BiasedKL
+    g = torch.Generator().manual_seed(23)
+    B, S, V = 4, 6, 29
+    logits = torch.randn(B, S, V, generator=g)
+    trg = torch.randint(2, V, (B, S), generator=g)
+    trg[1, 4:] = 1
+    trg[3, 2:] = 1
+    sampled = torch.randint(0, V, (B, S), generator=g)
+    score = torch.rand(B, S, generator=g)
+    up = torch.randn(B * S, generator=g)             # an arbitrary upstream gradient of the divergence's row sums
+    out = dict(logits=np_(logits), trg=np_(trg), sampled=np_(sampled), score=np_(score), up=np_(up))
+    with contextlib.redirect_stderr(io.StringIO()):
+        for tag in ("attached", "detached", "other"):
+            x = logits.clone().requires_grad_(True)
+            lp = torch.log_softmax(x, -1)
+            p = torch.gather(torch.exp(lp), 2, sampled.unsqueeze(-1)).squeeze(-1)
+            n = (trg != 1).sum(-1).reshape(-1, 1).float()
+            if tag == "other":
+                amp = torch.clamp(score * torch.sqrt(p) * 0.9 + 0.05, 0, 1)
+            else:
+                amp = torch.clamp(score * p * n, 0, 1)
+            if tag == "detached":
+                amp = amp.detach()
+            div = BiasedKL(0.7, 1)(lp, trg, sampled, amp)
+            (div.sum(-1) * up).sum().backward()
+            out[f"{tag}_amp"] = np_(amp)
+            out[f"{tag}_rows"] = np_(div.sum(-1))
+            out[f"{tag}_grad_logits"] = np_(x.grad)
+    np.savez_compressed(os.path.join(HERE, "biased_kl_forward.npz"), **out)
+
+
 def mha_cases():
     from model.multihead_attention import MultiheadedAttention
     out = {}
@@ -534,11 +569,15 @@ if __name__ == "__main__":
     if "--only-rl-loops" in sys.argv:
         rl_loops_cases()
         sys.exit(0)
+    if "--only-bkl" in sys.argv:
+        biased_kl_forward_cases()
+        sys.exit(0)
     if "--only-sample" in sys.argv:
         sample_clip_decode()
         sys.exit(0)
     kat()
     losses_random()
+    biased_kl_forward_cases()
     mha_cases()
     critic_case()
     agent_tiny()

@@ -224,7 +224,7 @@ static double time_case(const Case& c, const Buffers& b, int iters) {
 }
 
 static const int CODES256[] = {41, 22};
-static const int CODES128[] = {41, 22, 24};
+static const int CODES128[] = {41, 22, 24, 14};   // 14: the pair form (attention_pair.h)
 
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "check";
@@ -243,7 +243,7 @@ int main(int argc, char** argv) {
       make(c, b, 1234u + c.Sq + 7 * c.Sk);
       printf("form %d  B%d H%d Sq%d Sk%d mask%d spike%d qmask%d\n", c.form, c.B, c.H, c.Sq, c.Sk, c.maskmode, c.spike, c.qmask);
       const int* codes = c.form == 256 ? CODES256 : CODES128;
-      const int ncodes = c.form == 256 ? 2 : 3;
+      const int ncodes = c.form == 256 ? 2 : 4;
       for (int i = 0; i <= ncodes; ++i) {
         const int code = i < ncodes ? codes[i] : 0;
         bmhrl_attention_config(c.form, code);
@@ -275,7 +275,7 @@ int main(int argc, char** argv) {
       const double gf = 4.0 * c.B * c.H * (double)c.Sq * c.Sk * c.form / 1e9;
       printf("form %d B%d H%d Sq%d Sk%d mask%d (%.2f GF executed):", c.form, c.B, c.H, c.Sq, c.Sk, c.maskmode, gf);
       const int* codes = c.form == 256 ? CODES256 : CODES128;
-      const int ncodes = c.form == 256 ? 2 : 3;
+      const int ncodes = c.form == 256 ? 2 : 4;
       for (int i = 0; i < ncodes; ++i) {
         bmhrl_attention_config(c.form, codes[i]);
         if (launch(c, b, 0) != 0) { printf("  [%d] n/a", codes[i]); continue; }

@@ -11,7 +11,8 @@ if [ "$1" = "trace" ]; then   # the attention kernels with cycle stamps (-DBMHRL
   F="--offload-arch=gfx950 -O3 -std=c++17 -Wno-comment -DBMHRL_ATTN_TRACE -mllvm -amdgpu-codegenprepare-break-large-phis=false"
   $HIPCC $F -c bmhrl_amd/csrc/attention.hip -o tests/kbench/build/attention_t.o &
   $HIPCC $F -mllvm -amdgpu-mfma-vgpr-form -c bmhrl_amd/csrc/attention128.hip -o tests/kbench/build/attention128_t.o &
+  $HIPCC $F -c bmhrl_amd/csrc/attention128p.hip -o tests/kbench/build/attention128p_t.o &
   wait
   $HIPCC -O2 -std=c++17 -c tests/kbench/attn_bench.cpp -o tests/kbench/build/attn_bench.o
-  $HIPCC --offload-arch=gfx950 tests/kbench/build/attn_bench.o tests/kbench/build/attention_t.o tests/kbench/build/attention128_t.o -o tests/kbench/attn_bench_trace
+  $HIPCC --offload-arch=gfx950 tests/kbench/build/attn_bench.o tests/kbench/build/attention_t.o tests/kbench/build/attention128_t.o tests/kbench/build/attention128p_t.o -o tests/kbench/attn_bench_trace
 fi

@@ -751,6 +751,47 @@ def test_head_takes_dlogits_from_the_token_loss_node(dev):
     assert torch.equal(y[0], y[1]) and not F._GRAD_TWIN
 
 
+def test_sole_consumer_promise_is_checked_not_trusted(dev):
+    """TokenLossFn(sole_consumer=True) hands bf16 d logits to the worker head behind autograd's back and returns a placeholder as
+    the log-probs' gradient.  A broken promise -- a second consumer of the log-probs, a tensor hook that rewrites the gradient
+    -- must raise in the head's backward; a retained gradient shows NaN, never uninitialised memory (r03 review)."""
+    from bmhrl_amd import functional as F
+    torch.manual_seed(6)
+    B, L, d1, d2, V = 2, 5, 40, 24, 128
+    x0, g0 = torch.randn(B, L, d1, device=dev), torch.randn(B, L, d2, device=dev)
+    w0, b0 = torch.randn(V, d1 + d2, device=dev) * 0.1, torch.randn(V, device=dev) * 0.1
+    trg = torch.randint(2, V, (B, L), device=dev)
+
+    def head():
+        x, gc, w, b = (t.clone().requires_grad_(True) for t in (x0, g0, w0, b0))
+        return x, F.WorkerHeadFn.apply(x, gc, w, b)
+
+    # a second consumer: autograd sums the two gradients, the placeholder does not arrive
+    x, logp = head()
+    loss = F.TokenLossFn.apply(logp, trg, None, None, None, 0.7, 1, 1.0, None, True) + 0.1 * logp.sum()
+    with pytest.raises(RuntimeError, match="second consumer"):
+        loss.backward()
+    F._GRAD_TWIN.clear()
+    # a hook that rewrites the gradient
+    x, logp = head()
+    logp.register_hook(lambda g: g * 2)
+    with pytest.raises(RuntimeError, match="second consumer"):
+        F.TokenLossFn.apply(logp, trg, None, None, None, 0.7, 1, 1.0, None, True).backward()
+    F._GRAD_TWIN.clear()
+    # a view of the log-probs is not the head's tensor: the plain path, correct gradients
+    x, logp = head()
+    F.TokenLossFn.apply(logp.view(B, L, V)[:, :, :], trg, None, None, None, 0.7, 1, 1.0, None, True).backward()
+    gx_view = x.grad.clone()
+    x, logp = head()
+    F.TokenLossFn.apply(logp, trg, None, None, None, 0.7, 1, 1.0, None, False).backward()
+    assert rel_err(gx_view, x.grad) < 1e-6 and not F._GRAD_TWIN
+    # retain_grad: what is retained is the placeholder -- NaN, not garbage -- and the real gradients are unaffected
+    x, logp = head()
+    logp.retain_grad()
+    F.TokenLossFn.apply(logp, trg, None, None, None, 0.7, 1, 1.0, None, True).backward()
+    assert bool(torch.isnan(logp.grad).all()) and rel_err(x.grad, gx_view) < 4e-3 and not F._GRAD_TWIN
+
+
 def test_token_loss_node_equals_sum_over_n_tokens(dev, golden):
     """functional.TokenLossFn (row sums -> one-block reduce -> scalar, gradient scaled inside the kernel) == the loops'
     torch.sum(criterion(pred, y)) / (n_tokens * factor) over SmoothKLFn, value and gradient; against the oracle too."""
@@ -839,3 +880,54 @@ def test_head_loss_one_launch_equals_the_four_kernels(rows, V, pad_rows):
         assert torch.equal(gb2, gb)
         assert float((rl2 - row_loss).abs().max()) <= 2e-6 * float(row_loss.abs().max())
         assert abs(float(out2[0]) - float(out[0])) <= 2e-6 * abs(float(out[0]))
+
+
+@pytest.mark.parametrize("poison", ["inf", "-inf_all", "nan", "huge"])
+def test_head_loss_reports_a_non_finite_row_like_the_unfused_tail(dev, poison):
+    """A NaN / Inf logit (diverged training) must show in the loss of the one-launch tail exactly as in the four-kernel tail:
+    the rows are summed in 2^-32 fixed point there, and a non-finite row has no fixed-point image (r03 ADVICE: it came out as a
+    finite garbage number).  The step after it must be clean again (the flag word re-arms with the counter)."""
+    from bmhrl_amd import ops
+    rows, V, pad = 96, 1000, 1
+    g = torch.Generator().manual_seed(7)
+    logits = (torch.randn(rows, V, generator=g) * 3).to(dev)
+    trg = torch.randint(2, V, (rows,), generator=g).to(dev)
+    bad = logits.clone()
+    if poison == "inf":
+        bad[5, 17] = float("inf")
+    elif poison == "-inf_all":
+        bad[9, :] = float("-inf")
+    elif poison == "nan":
+        bad[40, 3] = float("nan")
+    else:
+        bad[3, int(trg[3])] = -3.0e38        # a finite logit whose row loss is beyond the fixed-point range
+    weight = torch.tensor([1.0], device=dev)
+    counter = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def fused(x):
+        rl = torch.empty(rows, device=dev)
+        out = torch.full((2,), 123.0, device=dev)
+        gb = torch.zeros(rows, V, dtype=torch.bfloat16, device=dev)
+        ops.head_loss(x.clone(), V, trg, 0.7, pad, weight, 1.0, None, rl, out, gb, V, counter, rows, V)
+        torch.cuda.synchronize()
+        return out[0].item()
+
+    def unfused(x):
+        ref = x.clone()
+        ops.log_softmax_(ref, V, rows, V)
+        rl = torch.empty(rows, device=dev)
+        ops.smooth_kl_fwd(ref, V, trg, None, None, None, 0.7, pad, -1, rl, None, rows, V)
+        out = torch.empty(2, device=dev)
+        ops.token_loss_reduce(rl, trg, rows, pad, weight, 1.0, out[0:1], out[1:2])
+        torch.cuda.synchronize()
+        return out[0].item()
+
+    want, got = unfused(bad), fused(bad)
+    if poison == "huge":        # a finite row beyond 2^20 saturates to +Inf (the float sum would be ~1e38: diverged either way)
+        assert want > 1e30 and got == float("inf"), (want, got)
+    else:
+        assert not math.isfinite(want)
+        assert (math.isnan(want) and math.isnan(got)) or want == got, (want, got)
+    assert int(counter.abs().sum()) == 0
+    clean = fused(logits)
+    assert math.isfinite(clean) and abs(clean - unfused(logits)) <= 2e-6 * abs(clean)

@@ -262,3 +262,22 @@ def test_biased_kl_loops_against_the_reference(golden):
         close(sr, g[f"sr{i}"], 1e-6)
         assert torch.equal(idx, T(g[f"sr_idx{i}"]))
     assert seen_empty_row0 and seen_no_segment
+
+
+@pytest.mark.parametrize("tag", ["attached", "detached", "other"])
+def test_biased_kl_forward_amplitude_is_an_argument(golden, tag):
+    """oracle.biased_kl_loss against the reference's BiasedKL.forward (tests/golden/biased_kl_forward.npz, loss/biased_kl.py:22-53)
+    with the amplitude attached to the prediction, detached, and attached through another function of it"""
+    g = golden("biased_kl_forward")
+    T = lambda k: torch.from_numpy(g[k])
+    x = T("logits").clone().requires_grad_(True)
+    lp = torch.log_softmax(x, -1)
+    p = torch.gather(torch.exp(lp), 2, T("sampled").unsqueeze(-1)).squeeze(-1)
+    n = (T("trg") != 1).sum(-1).reshape(-1, 1).float()
+    amp = torch.clamp(T("score") * torch.sqrt(p) * 0.9 + 0.05, 0, 1) if tag == "other" else torch.clamp(T("score") * p * n, 0, 1)
+    if tag == "detached":
+        amp = amp.detach()
+    div = O.biased_kl_loss(lp, T("trg"), T("sampled"), amp, 0.7, 1)
+    (div.sum(-1) * T("up")).sum().backward()
+    assert torch.allclose(div.sum(-1).detach(), T(f"{tag}_rows"), atol=1e-6)
+    assert torch.allclose(x.grad, T(f"{tag}_grad_logits"), atol=1e-6)
