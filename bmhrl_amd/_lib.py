@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
         ("aux", ptr), ("ldaux", i64), ("aux_sb1", i64), ("aux_sb2", i64),
         ("dropout_p", f32), ("seed", u64), ("drop_sb1", i64), ("drop_sb2", i64), ("drop_sm", i64), ("seed_dev", ptr),
         ("colsum", ptr), ("colsum_sb2", i64), ("bias_sb2", i64), ("colsum_sb1", i64), ("bias_sb1", i64),
+        ("split_ws", ptr), ("split_ws_elems", i64),
     ]
 
 

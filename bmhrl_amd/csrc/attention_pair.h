@@ -51,8 +51,9 @@ constexpr int P_IMG_BYTES = 4 * 32 * P_IMG_ROWB;  // 18 432 >= the 16 KiB of the
 constexpr int P_WORDS = 40;                       // ballot words of 256 keys
 constexpr int P_BAL = P_QIMG + P_IMG_BYTES;
 constexpr int P_ML = P_BAL + 2 * P_WORDS * 8;     // (max, sum) of every (wave, block, lane)
-constexpr int P_LDS = P_ML + 4 * 2 * 64 * 8;
+constexpr int P_KEEP = P_ML + 4 * 2 * 64 * 8;     // one byte per 4-key group: bit j = key 4 g + j is valid and not masked
 constexpr int P_MAX_SK = P_WORDS * 256 - 128;
+constexpr int P_LDS = P_KEEP + P_WORDS * 64;      // (256 keys per ballot word = 64 groups)
 static_assert(P_LDS <= 160 * 1024, "one workgroup per CU");
 
 // ---- MFMAs with explicit register classes.  Hazards (the compiler pads nothing around an asm statement):
@@ -220,11 +221,17 @@ __global__ __launch_bounds__(256, 1) void attn_pair128_kernel(const PairArgs p) 
       }
     }
     bool any_slow = false, any_valid = false;
+    unsigned nib = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool keep = i0 + e < p.Sk && ((v >> (8 * e)) & 0xffu) != 0;
       any_slow |= !keep;
       any_valid |= keep;
+      nib |= (keep ? 1u : 0u) << e;
+    }
+    if (tid + 256 * j < P_WORDS * 64) {
+      const unsigned ka = lds0 + P_KEEP + tid + 256 * j;
+      asm volatile("ds_write_b8 %0, %1" ::"v"(ka), "v"(nib) : "memory");
     }
     const uint64_t bs = __ballot(any_slow), bv = __ballot(any_valid);
     if (lane == 0 && 4 * j + ki < P_WORDS) {
@@ -294,30 +301,20 @@ __global__ __launch_bounds__(256, 1) void attn_pair128_kernel(const PairArgs p) 
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
   const float c_log2 = p.scale * LOG2E;
 
-  // scale + mask the raw scores of one tile through the mask bytes of the lane's 16 keys (rare path); returns the tile maximum
+  // scale + mask the raw scores of one tile (rare path: the tile holds a masked or padding key) through the keep bits the
+  // prologue left in LDS -- 8 bytes cover the tile's 32 keys, the lane's groups are bytes h + 2 g --; returns the tile maximum.
+  // (No global load here: an ordinary load would make the compiler drain the tile pieces in flight.)
   auto scale_scores = [&](const f32x16& raw, float (&sc)[16], const int k0) {
     float m_tile = -INFINITY;
-    const int key0 = k0 + 4 * h;
+    const uint64_t m8 = lds_u64(lds0 + P_KEEP + (k0 >> 2));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      uint32_t mk = 0x01010101u;
-      const int kk = key0 + 8 * g;
-      if (mrow_b != nullptr && kk < p.Sk) {
-        if (mask_al4 && kk + 4 <= p.Sk) {
-          mk = *reinterpret_cast<const uint32_t*>(mrow_b + kk);
-        } else {
-          mk = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (kk + e < p.Sk) mk |= (uint32_t)mrow_b[kk + e] << (8 * e);
-        }
-      }
+      const unsigned nib = (unsigned)(m8 >> (8 * (h + 2 * g))) & 0xfu;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int key = key0 + 8 * g + j;
-        const bool in = key < p.Sk;
-        const bool keep = in && ((mk >> (8 * j)) & 0xffu) != 0;
-        const float v = keep ? raw[4 * g + j] * c_log2 : (in ? NEG_MASK * LOG2E : -INFINITY);
+        const int key = k0 + 4 * h + 8 * g + j;
+        const bool keep = (nib >> j) & 1u;
+        const float v = keep ? raw[4 * g + j] * c_log2 : (key < Sk ? NEG_MASK * LOG2E : -INFINITY);
         sc[4 * g + j] = v;
         m_tile = fmaxf(m_tile, v);
       }

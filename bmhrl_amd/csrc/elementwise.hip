@@ -700,12 +700,18 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* _
     if (ob) ob[r * ldob + c] = (bf16_t)v;
   }
 }
+// Backward of the row gather: dx[s] = sum of dout[r] over the rows r with src[r] == s.  The row map of expand_goals sends a
+// run of CONSECUTIVE rows (a segment) to its last row and every other row to itself (or nowhere), so the owner of row s walks
+// down from s while the map still points at s and adds in that fixed order -- an activation gradient (the manager's goals) that
+// does not depend on the arrival order of atomics.  A general map (any row may point anywhere) would need the atomics back.
 __global__ void scatter_add_rows_kernel(const float* __restrict__ dout, const int32_t* __restrict__ src,
                                         float* __restrict__ dx, int D, long total) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / D;
-    const int s = src[r];
-    if (s >= 0) atomicAdd(dx + (long)s * D + (i % D), dout[i]);
+    const long s = i / D;
+    const int c = (int)(i - s * D);
+    float a = 0.f;
+    for (long r = s; r >= 0 && src[r] == (int32_t)s; --r) a += dout[r * D + c];
+    dx[i] = a;
   }
 }
 
@@ -1526,4 +1532,4 @@ extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 //     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce, bmhrl_fusion_tail_fwd / _bwd
 // 11: bmhrl_batch_head, bmhrl_smooth_kl_bwd loss_scale2, bmhrl_layernorm_fwd_groups / _bwd_groups, bmhrl_colsum_bf16_groups,
 //     bmhrl_cast_bf16_copies
-extern "C" int bmhrl_hip_abi_version(void) { return 13; }
+extern "C" int bmhrl_hip_abi_version(void) { return 14; }

@@ -11,6 +11,7 @@
 // Global -> register -> LDS staging is software pipelined one K-tile ahead (two LDS buffers, one barrier
 // per K-tile).  Roofline: MFMA-bound for the 1024-wide projections; HBM-bound for K <= 128.
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -33,9 +34,21 @@ struct GemmArgs {
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
   float* colsum; long cs_sb2, bias_sb2, cs_sb1, bias_sb1;
   int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16, fast_pd, tiles_mn;
+  float* split_ws;          // ordered K split: the splits' partial tiles [batch][split][M][N] (summed by splitk_reduce_kernel)
 };
 
 constexpr int BK = 64;
+
+// Tuning aid (-DBMHRL_GEMM_TRACE, tests/kbench/build.sh trace): cycle stamps of wave 0 of the first and the last workgroup of the
+// direct-to-LDS kernel -- entry, first loads requested, first tile published, main loop done, epilogue done.
+#ifdef BMHRL_GEMM_TRACE
+__device__ long long g_gemm_trace[2][8];
+#define BMHRL_GSTAMP(i)                                                                                   \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+    g_gemm_trace[blockIdx.x != 0][i] = (long long)__builtin_readcyclecounter();
+#else
+#define BMHRL_GSTAMP(i)
+#endif
 
 // ---- epilogue, shared by the two main loops.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
 // 4*(lane>>5)) go through LDS (`smem`: SMEM_ELEMS bf16 elements, free once every wave is past the main loop).
@@ -79,6 +92,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) stage_bf16(acc[mi][ni], mi, ni);
     __syncthreads();
+    if (p.dbg == 5) return;                        // (tuning aid: staging only)
     constexpr int G8 = BM * BN / 8 / 256;          // 16-byte groups per thread
 #pragma unroll
     for (int i = 0; i < G8; ++i) {
@@ -88,6 +102,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
       if (m < p.M && n < p.N) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(sCb + row * SCB + c8);
         bf16_t* dst = Cbf + (long)m * p.ldcb + n;
+        if (p.dbg == 4) { if (v[0] == (bf16_t)123.25f) dst[0] = v[0]; continue; }     // (tuning aid: the epilogue without its stores)
         if (n + 8 <= p.N) *reinterpret_cast<bf16x8*>(dst) = v;
         else for (int j = 0; j < 8 && n + j < p.N; ++j) dst[j] = v[j];
       }
@@ -196,6 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) stage(acc[mi][ni], mi, ni);
   __syncthreads();
+  if (p.dbg == 5) return;                          // (tuning aid: staging only)
 
   float* __restrict__ Cg = p.C ? p.C + b1 * p.c_sb1 + b2 * p.c_sb2 : nullptr;
   bf16_t* __restrict__ Cbg = p.Cb ? p.Cb + b1 * p.cb_sb1 + b2 * p.cb_sb2 : nullptr;
@@ -272,6 +288,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
           for (int j = 0; j < 4; ++j)
             o[j] = elem(kind, a4[j], b4[j], r4[j], x4[j], rv, rv2, m, n + j, ((keep4 >> (8 * j)) & 0xffu) != 0);
           cs4 += o;
+          if (p.dbg == 4) { if (o[0] == 123.25f && Cg) Cg[0] = o[0]; continue; }      // (tuning aid: the epilogue without its stores)
           if (Cg) {
             float* dst = Cg + (long)m * p.ldc + n;
             if (p.splits > 1) {
@@ -306,6 +323,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
       }
     }
   };
+  if (p.splits > 1 && p.split_ws) {
+    // ordered K split: the raw partial tile goes to this split's slab with plain stores; splitk_reduce_kernel adds the slabs in
+    // split order (and applies alpha / bias / residual / accumulate), so the result does not depend on who arrives when
+    float* __restrict__ slab = p.split_ws + (((long)(b1 * p.batch2 + b2) * p.splits + split) * p.M) * p.N;
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int row = idx / BN, col = idx % BN;
+      const int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) slab[(long)m * p.N + n] = sC[row * SC + col];
+    }
+    return;
+  }
   if (p.splits > 1) {
     // split-K partial sums: lane l adds column l of a row, so one wave instruction covers 256 contiguous bytes (the
     // shape float atomics run at full rate with); bias / residual are added by the first split only.
@@ -623,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin) / BK;                             // whole tiles only (host-checked)
   if (nk <= 0) return;
+  BMHRL_GSTAMP(0)
 
   // ---- staging: per-lane byte offsets from the operand base, fixed for the launch (rows / columns past the matrix edge
   // are clamped to valid memory: they only feed outputs that are never stored); the uniform base advances by one k-tile
@@ -788,10 +817,12 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   gsfor<0, NS - 1>([&](auto i_) {
     if (decltype(i_)::value < nk) stage(i_, decltype(i_)::value);
   });
+  BMHRL_GSTAMP(1)
   if (NS > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PT) : "memory");   // tile 0 (conservative when nk < NS-1: see below)
   if (NS == 2 || nk < NS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  BMHRL_GSTAMP(2)
   for (int t0 = 0; t0 < nk; t0 += NS) {
     gsfor<0, NS>([&](auto i_) {
       if (t0 + decltype(i_)::value < nk) step(i_, t0 + decltype(i_)::value);
@@ -800,7 +831,236 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();             // every wave is done with the stages: the epilogue reuses them
   asm volatile("" ::: "memory");
+  BMHRL_GSTAMP(3)
   gemm_epilogue<TM, TN, SMEM_ELEMS>(p, acc, smem, b1, b2, m0, n0, (int)blockIdx.y);
+  BMHRL_GSTAMP(4)
+}
+
+// ---- 128 x 128 tiles with EIGHT waves: two wave groups split every k-tile between them (intra-workgroup K split).
+// The shapes that give a CU exactly one 128 x 128 tile (4096 x 1024 outputs: 256 tiles) leave the four waves of the kernel above
+// alone on their SIMDs: a wave issues its 8 direct-to-LDS pieces, its 16 fragment reads and its 16 MFMAs of a k-tile in
+// order, the barrier at the end of the step exposes whatever the two-stage ring did not cover, and prologue and epilogue
+// have nothing beside them.  Their forward epilogues carry dropout and the residual, so a K split over WORKGROUPS (fp32
+// atomics) is not available.  Here waves 0-3 and 4-7 both own the whole tile (the same 2 x 2 wave layout) and take k-steps
+// {0, 1} and {2, 3} of every 64-deep k-tile: 8 MFMAs, 8 fragment reads and 4 pieces per wave and tile, two waves per SIMD that
+// cover each other's waits, three stages with the loads of tile t + 2 in flight across the barrier of step t.  The two
+// partial tiles meet in LDS (group 1 stores, group 0 adds: lane-private 16-byte slots, no conflicts), then group 0 runs the
+// unchanged epilogue while group 1 has ended (a barrier counts the waves that are still there).
+template <bool AT, bool BT>
+__global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(const GemmArgs p) {
+  constexpr int TM = 2, TN = 2, NS = 3, NW = 8;
+  constexpr int BM = 128, BN = 128;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int EPI_ELEMS = BM * (BN + 4) * 2;
+  constexpr int SMEM_ELEMS = (NS * STAGE_BYTES / 2) > EPI_ELEMS ? (NS * STAGE_BYTES / 2) : EPI_ELEMS;
+  static_assert(4 * 64 * 256 <= SMEM_ELEMS * 2, "the partial tile of wave group 1 fits the stages");
+
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM_ELEMS];
+  char* const sbase = reinterpret_cast<char*>(smem);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sbase;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int bz = blockIdx.z, b1 = bz / p.batch2, b2 = bz % p.batch2;
+  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A + b1 * p.a_sb1 + b2 * p.a_sb2);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B + b1 * p.b_sb1 + b2 * p.b_sb2);
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const int nk = p.K / BK;                                           // no K split over workgroups; whole tiles (host-checked)
+  BMHRL_GSTAMP(0)
+
+  // ---- staging: the stage images of gemm_glds_kernel, filled by eight waves (2 + 2 pieces each)
+  constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;
+  unsigned a_off[PA], b_off[PB];
+  auto piece_off = [&](const bool trans, const int R, const int i, const int r0, const int rmax, const int rmax8, const long ld) {
+    if (!trans) {                       // [R rows][64 k]: 8 rows per piece
+      const int row = wave * (R / NW) + 8 * i + (lane >> 3), pc = lane & 7;
+      const int sc = pc ^ ((row >> 1) & 7);
+      return (unsigned)((long)min(r0 + row, rmax - 1) * ld * 2 + sc * 16);
+    }
+    const int cpr = R / 8, rpp = 64 / cpr;                             // chunks per row, k-rows per piece
+    const int krow = wave * (64 / NW) + rpp * i + lane / cpr, pc = lane % cpr;
+    const int sc = pc ^ ((krow & 3) << 2);
+    return (unsigned)((long)krow * ld * 2 + (long)min(r0 + sc * 8, rmax8 - 8) * 2);
+  };
+#pragma unroll
+  for (int i = 0; i < PA; ++i) a_off[i] = piece_off(AT, BM, i, m0, p.M, M8, p.lda);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) b_off[i] = piece_off(BT, BN, i, n0, p.N, N8, p.ldb);
+  const long a_step = AT ? (long)BK * p.lda * 2 : (long)BK * 2, b_step = BT ? (long)BK * p.ldb * 2 : (long)BK * 2;
+  char* const a_dst = sbase + wave * PA * 1024;
+  char* const b_dst = sbase + A_BYTES + wave * PB * 1024;
+  auto stage = [&](auto st_, const int t) {
+    constexpr int ST = decltype(st_)::value;
+    auto sgpr_ptr = [](const char* q) {
+      const uint64_t u = reinterpret_cast<uint64_t>(q);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+      return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    const char* ab = sgpr_ptr(Ag + (long)t * a_step);
+    const char* bb = sgpr_ptr(Bg + (long)t * b_step);
+    gsfor<0, PA>([&](auto i) {
+      constexpr int I = decltype(i)::value;
+      unsigned o = a_off[I];
+      asm volatile("" : "+v"(o));
+      gemm_glds16<0>(ab + o, a_dst + ST * STAGE_BYTES + I * 1024);
+    });
+    gsfor<0, PB>([&](auto i) {
+      constexpr int I = decltype(i)::value;
+      unsigned o = b_off[I];
+      asm volatile("" : "+v"(o));
+      gemm_glds16<0>(bb + o, b_dst + ST * STAGE_BYTES + I * 1024);
+    });
+  };
+
+  // ---- fragment addresses (stage 0), as gemm_glds_kernel; this group's k-steps are 2 grp and 2 grp + 1
+  constexpr int NA = AT ? TM : 2, NB = BT ? TN : 2;
+  unsigned a_addr0[NA], b_addr0[NB];
+  if constexpr (!AT) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+      a_addr0[k2] = lds0 + (wm * 64 + r32) * 128 + (((2 * (2 * grp + k2) + h) ^ ((r32 >> 1) & 7)) << 4);
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int c = wm * 8 + 4 * i + 2 * g1 + (p4 >> 1);
+      a_addr0[i] = lds0 + (8 * h + q4 + 32 * grp) * (BM * 2) + ((c ^ (q4 << 2)) << 4) + ((p4 & 1) << 3);
+    }
+  }
+  if constexpr (!BT) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+      b_addr0[k2] = lds0 + A_BYTES + (wn * 64 + r32) * 128 + (((2 * (2 * grp + k2) + h) ^ ((r32 >> 1) & 7)) << 4);
+  } else {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int c = wn * 8 + 4 * i + 2 * g1 + (p4 >> 1);
+      b_addr0[i] = lds0 + A_BYTES + (8 * h + q4 + 32 * grp) * (BN * 2) + ((c ^ (q4 << 2)) << 4) + ((p4 & 1) << 3);
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr int RA = AT ? 2 : 1, RBn = BT ? 2 : 1;
+  constexpr int PER_KS = TM * RA + TN * RBn;
+  auto compute = [&](auto st_) {
+    constexpr int ST = decltype(st_)::value;
+    bf16x8 af[2][TM], bfr[2][TN];
+    unsigned a_addr[NA], b_addr[NB];                         // (the stage offset does not fit the 16-bit immediate for stage 2)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_addr[i] = a_addr0[i] + ST * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_addr[i] = b_addr0[i] + ST * STAGE_BYTES;
+    auto read_ks = [&](auto k2_) {                           // k-step 2 grp + K2 of the tile
+      constexpr int K2 = decltype(k2_)::value;
+      gsfor<0, TM>([&](auto i_) {
+        constexpr int I = decltype(i_)::value;
+        if constexpr (!AT) {
+          af[K2][I] = gemm_lds128<I * 32 * 128>(a_addr[K2]);
+        } else {
+          constexpr int RB = BM * 2;
+          af[K2][I] = join8(gemm_ldstr<K2 * 16 * RB>(a_addr[I]), gemm_ldstr<(K2 * 16 + 4) * RB>(a_addr[I]));
+        }
+      });
+      gsfor<0, TN>([&](auto i_) {
+        constexpr int I = decltype(i_)::value;
+        if constexpr (!BT) {
+          bfr[K2][I] = gemm_lds128<I * 32 * 128>(b_addr[K2]);
+        } else {
+          constexpr int RB = BN * 2;
+          bfr[K2][I] = join8(gemm_ldstr<K2 * 16 * RB>(b_addr[I]), gemm_ldstr<(K2 * 16 + 4) * RB>(b_addr[I]));
+        }
+      });
+    };
+    read_ks(IC<0>{});
+    read_ks(IC<1>{});
+    gsfor<0, 2>([&](auto k2_) {
+      constexpr int K2 = decltype(k2_)::value;
+      constexpr int LEFT = K2 == 0 ? PER_KS : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(af[K2][0]), "+v"(af[K2][1]), "+v"(bfr[K2][0]), "+v"(bfr[K2][1]) : "n"(LEFT));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[K2][mi], bfr[K2][ni], acc[mi][ni], 0, 0, 0);
+    });
+  };
+
+  constexpr int PT = PA + PB;
+  auto step = [&](auto st_, const int t) {
+    constexpr int ST = decltype(st_)::value;
+    constexpr int NXT = (ST + NS - 1) % NS;
+    const bool more = t + NS - 1 < nk;
+    if (more) stage(IC<NXT>{}, t + NS - 1);
+    compute(st_);
+    if (t + 1 < nk) {
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+  gsfor<0, NS - 1>([&](auto i_) {
+    if (decltype(i_)::value < nk) stage(i_, decltype(i_)::value);
+  });
+  BMHRL_GSTAMP(1)
+  if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  BMHRL_GSTAMP(2)
+  for (int t0 = 0; t0 < nk; t0 += NS) {
+    gsfor<0, NS>([&](auto i_) {
+      if (t0 + decltype(i_)::value < nk) step(i_, t0 + decltype(i_)::value);
+    });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();             // every wave is done with the stages
+  asm volatile("" ::: "memory");
+  BMHRL_GSTAMP(3)
+  // ---- the two partial tiles: group 1 -> LDS (16 bytes per lane and slot: wave-private, conflict free) -> group 0
+  f32x4* xch = reinterpret_cast<f32x4*>(sbase) + w4 * 16 * 64 + lane;
+  if (grp == 1) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+          xch[((mi * TN + ni) * 4 + g) * 64] = v;
+        }
+  }
+  __syncthreads();
+  if (grp == 1) return;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = xch[((mi * TN + ni) * 4 + g) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] += v[e];
+      }
+  __syncthreads();                          // (the four remaining waves: the epilogue stages through the same memory)
+  gemm_epilogue<TM, TN, SMEM_ELEMS>(p, acc, smem, b1, b2, m0, n0, 0);
+  BMHRL_GSTAMP(4)
 }
 
 // direct-to-LDS main loop: whole k-tiles only (no zero fill of a ragged reduction tail) and 32-bit lane offsets
@@ -835,6 +1095,20 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
     // at 480 x 1024 x 1024; those launches sit on their fixed costs, not on the depth of the ring.)
     int ns = TM == 1 && splits == 1 && blocks <= 448 ? 4 : 2;
     if (force_ns) ns = TM == 1 ? (force_ns >= 4 ? 4 : 2) : 2;
+    // eight waves per 128 x 128 tile (gemm_glds8_kernel) when a CU gets at most one tile: BMHRL_GEMM_W8 = 0 off, 1 (default) on
+    // for grids of up to W8_MAX workgroups, 2 always
+    static const int w8 = getenv("BMHRL_GEMM_W8") ? atoi(getenv("BMHRL_GEMM_W8")) : 1;
+    static const long w8_max = getenv("BMHRL_GEMM_W8MAX") ? atol(getenv("BMHRL_GEMM_W8MAX")) : 256;
+    if constexpr (TM == 2 && TN == 2) {
+      if (w8 && splits == 1 && a.K >= 2 * BK && (w8 == 2 || blocks <= w8_max)) {
+        dim3 block8(512);
+        if (!a_trans && !b_trans) hipLaunchKernelGGL((gemm_glds8_kernel<false, false>), grid, block8, 0, s, p);
+        else if (!a_trans && b_trans) hipLaunchKernelGGL((gemm_glds8_kernel<false, true>), grid, block8, 0, s, p);
+        else if (a_trans && !b_trans) hipLaunchKernelGGL((gemm_glds8_kernel<true, false>), grid, block8, 0, s, p);
+        else hipLaunchKernelGGL((gemm_glds8_kernel<true, true>), grid, block8, 0, s, p);
+        return hipGetLastError();
+      }
+    }
 #define BMHRL_GLDS(AT_, BT_)                                                                                    \
     do {                                                                                                          \
       if (TM == 1 && ns == 4) hipLaunchKernelGGL((gemm_glds_kernel<TM, TN, AT_, BT_, TM == 1 ? 4 : 2>), grid, block, 0, s, p); \
@@ -942,6 +1216,24 @@ __global__ __launch_bounds__(1024) void colsum_ordered_kernel(const GemmArgs p, 
     }
 }
 
+// Second pass of the ordered K split: C = [C +] alpha * sum_s slab_s (+ bias) (+ residual), slabs added in split order.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, int batch) {
+  const long per = (long)p.M * p.N, total = per * batch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long bz = i / per, r = i - bz * per;
+    const int m = (int)(r / p.N), n = (int)(r - (long)m * p.N);
+    const int b1 = (int)(bz / p.batch2), b2 = (int)(bz % p.batch2);
+    const float* slab = p.split_ws + bz * p.splits * per + r;
+    float x = 0.f;
+    for (int sidx = 0; sidx < p.splits; ++sidx) x += slab[sidx * per];
+    x *= p.alpha;
+    if (p.bias) x += p.bias[b1 * p.bias_sb1 + b2 * p.bias_sb2 + n];
+    if (p.residual) x += p.residual[b1 * p.r_sb1 + b2 * p.r_sb2 + (long)m * p.ldr + n];
+    float* dst = p.C + b1 * p.c_sb1 + b2 * p.c_sb2 + (long)m * p.ldc + n;
+    *dst = p.accumulate ? *dst + x : x;
+  }
+}
+
 }  // namespace
 
 // how many K splits bmhrl_gemm uses for a plain fp32 (M, N) = A^T-style product with allow_split_k set: 1 means every element
@@ -998,11 +1290,30 @@ int prepare(const bmhrl_gemm_desc* d, GemmArgs& a, TilePlan& tp, int& batch) {
               (d->epilogue == BMHRL_EPI_DSCORE && out_ok && d->aux && al(d->aux, 16) && d->ldaux % 8 == 0 &&
                d->aux_sb1 % 8 == 0 && d->aux_sb2 % 8 == 0 && (!d->mask || d->mask_sm == 0));
   const bool can_split = d->allow_split_k && d->C && !d->Cb && d->epilogue == BMHRL_EPI_LINEAR && !d->relu && !d->mask &&
-                         d->dropout_p == 0.f && !d->accumulate && !d->colsum;
+                         d->dropout_p == 0.f && (!d->accumulate || d->split_ws) && !d->colsum;
   tp = tile_plan(d->M, d->N, d->K, batch, can_split);
+  // ordered K split: only with a workspace that holds every split's partial tile
+  a.split_ws = (tp.splits > 1 && d->split_ws && d->split_ws_elems >= (int64_t)tp.splits * batch * d->M * d->N) ? d->split_ws : nullptr;
+  if (tp.splits > 1 && d->accumulate && !a.split_ws) return -22;
   return 0;
 }
 }  // namespace
+
+void gemm_trace_dump(const GemmArgs& a, hipStream_t stream) {
+#ifdef BMHRL_GEMM_TRACE
+  if (getenv("BMHRL_GEMM_TRACE")) {
+    long long hh[2][8];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_gemm_trace), sizeof(hh));
+    for (int w = 0; w < 2; ++w)
+      fprintf(stderr, "gemm trace (%s block, M %d N %d K %d): setup %lld  first tile %lld  loop %lld  epilogue %lld  total %lld\n",
+              w ? "last" : "first", a.M, a.N, a.K, hh[w][1] - hh[w][0], hh[w][2] - hh[w][1], hh[w][3] - hh[w][2], hh[w][4] - hh[w][3],
+              hh[w][4] - hh[w][0]);
+  }
+#else
+  (void)a; (void)stream;
+#endif
+}
 
 extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   GemmArgs a;
@@ -1020,6 +1331,14 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
     hipLaunchKernelGGL(colsum_ordered_kernel, dim3((unsigned)((full.N + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, full, d->batch1);
     e = hipGetLastError();
   }
+  if (e == hipSuccess && a.split_ws) {
+    GemmArgs r = a;
+    r.splits = tp.splits;
+    const long total = (long)batch * a.M * a.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, r, batch);
+    e = hipGetLastError();
+  }
+  gemm_trace_dump(a, (hipStream_t)stream);
   return hip_status(e);
 }
 
@@ -1043,7 +1362,7 @@ extern "C" int bmhrl_gemm_group(const bmhrl_gemm_desc* d, int32_t n, bmhrl_strea
     if (const int rc = prepare(d + i, *ps[i], tp, batch)) return rc;
     GemmArgs& p = *ps[i];
     same = same && !tp.big && !tp.mid && d[i].a_trans == d[0].a_trans && d[i].b_trans == d[0].b_trans &&
-           !uses_glds(p, d[i].a_trans, d[i].b_trans);
+           !uses_glds(p, d[i].a_trans, d[i].b_trans) && p.split_ws == nullptr;
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_mn = p.tiles_m * ((p.N + 63) / 64);
     p.splits = tp.splits;

@@ -512,6 +512,21 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
 
 
 # ------------------------------------------------------------------------------------------------ linear helpers
+# K-split products on the ACTIVATION path (d x of the paired caption projections, d cat[x, goal] of the vocabulary head: few
+# output tiles over a long reduction) sum their splits through a workspace in split order instead of fp32 atomics: the
+# activation gradients -- and with them everything upstream -- no longer depend on the order the workgroups arrive in.  Leaf
+# weight gradients keep the atomics (nothing reads them but the optimizer).  BMHRL_ORDERED_DX=0: atomics there too (A/B).
+ORDERED_DX = os.environ.get("BMHRL_ORDERED_DX", "1") == "1"
+
+
+def _split_ws(M, N, K, batch, device):
+    """workspace for an ordered K split of an (M, N) fp32 product over K, or None when the product does not split"""
+    if not ORDERED_DX:
+        return None
+    n = ops.gemm_splits(M, N, K, batch)
+    return SCRATCH.f32(n * batch * M * N, device=device, zero=False) if n > 1 else None
+
+
 def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx, dx_f32=None, dx_bf16=None, lddxb=0,
                 dx_epilogue=ops.EPI_LINEAR, dx_alpha=1.0, dx_aux=None, ldaux=0, dx_drop=0.0, dx_seed=0,
                 dy_off=0, x_off=0, w_off=0, dx_accumulate=False, dx_colsum=None, dx_split_k=False, leaf=None):
@@ -530,10 +545,12 @@ def _linear_bwd(dyb, ldy, rows, N, xb, ldx, K, wb, *, need_dw, need_db, need_dx,
         db = SCRATCH.f32(N, device=dev)
         ops.colsum_bf16(dyb, ldy, db, True, rows, N, dy_off=dy_off)
     if need_dx:
+        ws = _split_ws(rows, K, N, 1, dev) if dx_split_k else None
         ops.gemm(dyb, wb, rows, K, N, lda=ldy, ldb=wb.shape[1], a_off=dy_off, b_off=w_off, b_trans=True, C_f32=dx_f32,
                  ldc=K, C_bf16=dx_bf16, ldcb=lddxb, epilogue=dx_epilogue, alpha=dx_alpha, aux=dx_aux, ldaux=ldaux,
                  dropout_p=dx_drop, seed=dx_seed, seed_dev=SEEDS.dev, accumulate=dx_accumulate, colsum=dx_colsum,
-                 allow_split_k=dx_split_k)            # (dx_split_k: dx_f32 is ZEROED -- few output tiles, long reduction)
+                 allow_split_k=dx_split_k, split_ws=ws)   # (dx_split_k: few output tiles over a long reduction; dx_f32 is
+                                                           #  zeroed for the case that the split runs on atomics)
     return dw, db
 
 
@@ -1089,7 +1106,8 @@ class PairMemAttnFn(torch.autograd.Function):
         ops.gemm_flush(leaf)
         dxn = SCRATCH.f32(2 * R, dq, device=dev)         # (zeroed: split K, as in PairSelfAttnFn)
         ops.gemm(dQb, w_q, R, dq, D, lda=D, ldb=w_q.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * D),
-                 b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True)
+                 b_strides=(0, D * w_q.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True,
+                 split_ws=_split_ws(R, dq, D, 2, dev))
         if self_att:                                    # the keys / values are LN(x) too: each half its own
             grad_mem(dxn, (0, R * dq), Sk * dm, (True, True))
         dx2 = torch.empty(2, B, L, dq, device=dev)
@@ -1180,7 +1198,8 @@ class PairSelfAttnFn(torch.autograd.Function):
         ops.gemm_flush(leaf)
         dxn = SCRATCH.f32(2 * R, dq, device=dev)         # (zeroed: 80 output tiles over a reduction of 3 D -> split K)
         ops.gemm(dQKV, w_qkv, R, dq, 3 * D, lda=3 * D, ldb=w_qkv.shape[1], b_trans=True, batch=(1, 2), a_strides=(0, R * 3 * D),
-                 b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True)
+                 b_strides=(0, 3 * D * w_qkv.shape[1]), C_f32=dxn, ldc=dq, c_strides=(0, R * dq), allow_split_k=True,
+                 split_ws=_split_ws(R, dq, 3 * D, 2, dev))
         dx2 = torch.empty(2, B, L, dq, device=dev)
         out = []
         dlnw2, dlnb2 = SCRATCH.f32(2 * dq, device=dev), SCRATCH.f32(2 * dq, device=dev)

@@ -51,8 +51,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
          r_strides=(0, 0), mask=None, mask_sb1=0, mask_sm=0, rowvec=None, rowvec2=None, rv_strides=(0, 0),
          aux=None, ldaux=0, aux_strides=(0, 0), aux_off=0, dropout_p=0.0, seed=0, seed_dev=None, drop_strides=(0, 0, 0), allow_split_k=False,
          colsum: Optional[torch.Tensor] = None, colsum_off=0, colsum_sb2=0, bias_sb2=0, colsum_sb1=0, bias_sb1=0,
-         defer: Optional[list] = None) -> None:
+         defer: Optional[list] = None, split_ws: Optional[torch.Tensor] = None) -> None:
     """C[b] = epilogue(A[b] @ B[b]); offsets are in elements from the tensors' data pointers.
+    split_ws: fp32 workspace of >= gemm_splits(M, N, K, batch) * batch * M * N elements: a K split then runs as partial tiles +
+    an ordered second pass instead of fp32 atomics (reproducible; C needs no zeroing).
     defer: a list -- the problem is appended to it instead of launched; gemm_flush(list) then launches up to four of them as
     ONE kernel (bmhrl_gemm_group: leaf products nothing in between depends on)."""
     _need_cuda(A, B, C_f32, C_bf16)
@@ -74,6 +76,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, lda: int, 
     d.drop_sb1, d.drop_sb2, d.drop_sm = drop_strides
     d.colsum = None if colsum is None else colsum.data_ptr() + 4 * colsum_off; d.colsum_sb2 = colsum_sb2
     d.bias_sb2 = bias_sb2; d.bias_sb1 = bias_sb1; d.colsum_sb1 = colsum_sb1
+    d.split_ws = _p(split_ws); d.split_ws_elems = 0 if split_ws is None else split_ws.numel()
     if defer is not None and _GROUP_LEAVES:
         defer.append((d, (A, B, C_f32, C_bf16, bias, residual, mask, rowvec, rowvec2, aux, seed_dev, colsum)))   # (operands kept alive)
         return
@@ -94,6 +97,17 @@ def gemm_flush(deferred: list) -> None:
 
 
 _SPLITS = {}
+
+
+def gemm_splits(M: int, N: int, K: int, batch: int = 1) -> int:
+    """K splits the launcher uses for a plain fp32 (M, N) output over a reduction of K with allow_split_k (bmhrl_gemm_splits)"""
+    key = (M, N, K, batch, "n")
+    r = _SPLITS.get(key)
+    if r is None:
+        r = _SPLITS[key] = int(_lib.load().bmhrl_gemm_splits(M, N, K, batch))
+        if r < 1:
+            raise RuntimeError(f"bmhrl_gemm_splits{key[:4]} failed: {r}")
+    return r
 
 
 def gemm_overwrites(M: int, N: int, K: int, batch: int = 1) -> bool:

@@ -64,6 +64,10 @@ typedef struct bmhrl_gemm_desc {
                                                      gradient of the layer whose dY this GEMM writes); not with split-K */
   int64_t bias_sb2;                               /* bias of batch entry (b1, b2) starts at bias + b1*bias_sb1 + b2*bias_sb2 (per-head bias slices) */
   int64_t colsum_sb1, bias_sb1;                   /* batch1 strides of colsum / bias (two weight sets in one launch: ABI 8) */
+  float* split_ws; int64_t split_ws_elems;        /* optional workspace of >= bmhrl_gemm_splits() * batch1 * batch2 * M * N floats
+                                                     (ABI 14): a K split then stores its partial tiles there and a second launch
+                                                     adds them in split order -- C needs no zeroing, `accumulate` is allowed, and
+                                                     the result is the same from run to run (fp32 atomics are not) */
 } bmhrl_gemm_desc;
 
 int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream);
@@ -328,6 +332,9 @@ int bmhrl_expand_goals_explore(const int32_t* seg, const float* x, int32_t* src,
                                const uint64_t* seed_dev, float* noise_out, bmhrl_stream_t stream);
 int bmhrl_gather_rows(const float* x, const int32_t* src, float* out, void* out_bf16, int64_t ldob, int64_t rows,
                       int32_t D, bmhrl_stream_t stream);
+/* backward of the gather along a row map of bmhrl_expand_goals[_index]: dx[s] = sum of dout[r] over src[r] == s, every row of dx
+ * written.  The map's structure is used (a run of consecutive rows points at its LAST row, other rows at themselves or at -1):
+ * the sum runs in row order, no atomics -- the manager's goal gradient is the same from run to run. */
 int bmhrl_scatter_add_rows(const float* dout, const int32_t* src, float* dx, int64_t rows, int32_t D,
                            bmhrl_stream_t stream);
 

@@ -169,6 +169,11 @@ int main(int argc, char** argv) {
         {480, 1024, 300, 0, 0, 1, 1, 0, "ragged K (old loop)"}, {257, 129, 100, 1, 1, 1, 0, 0, "ragged all tt"},
         {4096, 3072, 1024, 0, 0, 1, 1, 0, "V qkv"},        {800, 800, 256, 0, 0, 16, 1, 0, "attn S"},
         {800, 256, 800, 1, 1, 16, 1, 0, "attn dV (K=800: old loop)"},
+        // 256 tiles of 128 x 128: the eight-wave kernel (gemm_glds8_kernel), every operand layout, ragged edges, a batch
+        {2048, 2048, 512, 0, 0, 1, 1, 0, "8 waves nn"},   {2048, 2048, 512, 0, 1, 1, 0, 0, "8 waves nt"},
+        {2048, 2048, 512, 1, 0, 1, 0, 0, "8 waves tn"},   {2048, 2048, 512, 1, 1, 1, 1, 0, "8 waves tt"},
+        {2000, 1990, 192, 0, 0, 1, 0, 0, "8 waves ragged nn"}, {2000, 1990, 192, 1, 1, 1, 0, 0, "8 waves ragged tt"},
+        {1000, 1000, 128, 0, 1, 4, 1, 0, "8 waves batch nt"},
     };
     bool all_ok = true;
     for (const Shape& s : shapes) {
@@ -210,6 +215,20 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-  fprintf(stderr, "usage: gemm_bench check | time [iters]\n");
+  if (mode == "one" && argc >= 9) {      // one M N K at bt nb out_bf16 [iters]   (with the trace build: BMHRL_GEMM_TRACE=1 prints stamps)
+    Shape s{atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), 0, "one"};
+    const int iters = argc > 9 ? atoi(argv[9]) : 20;
+    Run r;
+    make(s, r, 5u);
+    if (launch(s, r, 0) != 0) { printf("launch failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
+    const double us = time_shape(s, r, iters);
+    const double gf = 2.0 * s.M * s.N * (double)s.K * s.nb / 1e9;
+    printf("M=%d N=%d K=%d at=%d bt=%d nb=%d %s %8.1f us %7.1f TF/s\n", s.M, s.N, s.K, s.at, s.bt, s.nb, s.out_bf16 ? "bf16" : "f32 ", us,
+           gf / us * 1e3);
+    release(r);
+    return 0;
+  }
+  fprintf(stderr, "usage: gemm_bench check | time [iters] | one M N K at bt nb out_bf16 [iters]\n");
   return 2;
 }
