@@ -44,6 +44,8 @@ def parse():
                          "train_bimodal_bl with synthetic rewards (biased KL of sampled tokens + value-head update)")
     ap.add_argument("--eager", action="store_true", help="launch kernels step by step instead of replaying the HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exploration", action="store_true",
+                    help="A/B aid: the manager's exploration noise off (the reference's warmstart step has it ON, the default here)")
     ap.add_argument("--cpu-batch", type=int, default=16, help="batch of the bounded CPU-oracle sample (default: the full B=16 step)")
     return ap.parse_args()
 
@@ -290,7 +292,8 @@ def main():
     b = syn.synthetic_batch(args.batch, args.tv, args.ta, args.len, args.vocab, seed=rank)
     rewards = syn.synthetic_rewards(args.batch, b["captions"].shape[1] - 1, seed=2 + rank).to(dev) if rl else None
     trainer = CaptionTrainer(cfg, args.vocab, dev, lr=1e-4, phase="worker" if rl else "warmstart",
-                             reward_fn=(lambda sampled, captions: rewards) if rl else None)
+                             reward_fn=(lambda sampled, captions: rewards) if rl else None,
+                             exploration=False if args.no_exploration else None)
     trainer.agent.train()
     if rl:
         trainer.value_net.train()

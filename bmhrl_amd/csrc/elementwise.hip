@@ -494,8 +494,32 @@ __global__ void cast_colsum_kernel(const float* __restrict__ x, long ldx, bf16_t
   colsum += grp * cs_stride;
   const bool vec = (ldx & 3) == 0 && (ldy & 3) == 0 && col + 4 <= cols && (((uintptr_t)x & 15) | ((uintptr_t)y & 7)) == 0;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  long r_first = r0 + ry;
+  const long r_end = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  if (col < cols && vec) {
+    // four rows per pass, every load of a pass requested before its first store: a loop that loads, converts and stores row by
+    // row waits for the store of the row before in front of every load (vmcnt counts stores too) -- two round trips per row
+    for (; r_first + 3 * rl < r_end; r_first += 4 * rl) {
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(x + (r_first + u * rl) * ldx + col);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long r = r_first + u * rl;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float w = t[u][j] * scale;
+          if (p > 0.f) w *= dropout_scale(p, seed, (uint64_t)r * cols + col + j);
+          o[j] = (bf16_t)w;
+          acc[j] += (float)o[j];
+        }
+        *reinterpret_cast<bf16x4*>(y + r * ldy + col) = o;
+      }
+    }
+  }
   if (col < cols) {
-    for (long r = r0 + ry; r < r0 + rows_per_block && r < rows; r += rl) {
+    for (long r = r_first; r < r_end; r += rl) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (vec) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(x + r * ldx + col);

@@ -74,23 +74,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     const float* __restrict__ bp = p.bias ? p.bias + b1 * p.bias_sb1 + b2 * p.bias_sb2 : nullptr;
     const uint64_t seedf = p.seed + ((p.dropout_p > 0.f && p.seed_dev) ? p.seed_dev[0] : 0ull);
     const uint64_t dbase = (uint64_t)b1 * p.drop_sb1 + (uint64_t)b2 * p.drop_sb2;
-    auto stage_bf16 = [&](const f32x16& av, const int mi, const int ni) {
-      const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
-      const float bias = (bp && n < p.N) ? bp[n] : 0.f;
-      const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+    // (the bias values of the lane's TN columns are requested together, and the uniform relu / dropout switches are decided
+    // ONCE: a scalar branch per element -- two per element, 128 per wave at 128 x 128 -- cost more than the staging itself)
+    float biasv[TN];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        float v = av[r] * p.alpha + bias;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.dropout_p > 0.f) v *= dropout_scale(p.dropout_p, seedf, dbase + (uint64_t)(m0 + row) * p.drop_sm + n);
-        sCb[row * SCB + col] = (bf16_t)v;
-      }
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = n0 + wn * 32 * TN + ni * 32 + r32;
+      biasv[ni] = (bp && n < p.N) ? bp[n] : 0.f;
+    }
+    auto stage_bf16 = [&](auto relu_, auto drop_) {
+      constexpr bool RELU = decltype(relu_)::value, DROP = decltype(drop_)::value;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          const f32x16& av = acc[mi][ni];
+          const int col = wn * 32 * TN + ni * 32 + r32, n = n0 + col;
+          const int row0 = wm * 32 * TM + mi * 32 + 4 * h;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            float v = av[r] * p.alpha + biasv[ni];
+            if constexpr (RELU) v = fmaxf(v, 0.f);
+            if constexpr (DROP) v *= dropout_scale(p.dropout_p, seedf, dbase + (uint64_t)(m0 + row) * p.drop_sm + n);
+            sCb[row * SCB + col] = (bf16_t)v;
+          }
+        }
     };
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) stage_bf16(acc[mi][ni], mi, ni);
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (p.dropout_p > 0.f) { if (p.relu) stage_bf16(T_{}, T_{}); else stage_bf16(F_{}, T_{}); }
+    else { if (p.relu) stage_bf16(T_{}, F_{}); else stage_bf16(F_{}, F_{}); }
     __syncthreads();
     if (p.dbg == 5) return;                        // (tuning aid: staging only)
     constexpr int G8 = BM * BN / 8 / 256;          // 16-byte groups per thread
@@ -257,6 +271,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   // sharing a column group are combined through LDS: one atomic per column per tile
   float* __restrict__ CSg = p.colsum ? p.colsum + b1 * p.cs_sb1 + b2 * p.cs_sb2 : nullptr;
   f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
+  // (r04: a two-pass form of this loop -- every global operand of a thread's 16 row pieces requested first, then compute + stores
+  // -- was built against the suspicion that the per-piece conditional loads make every piece wait for the stores of the one
+  // before (vmcnt counts stores): 28.8 vs 26.2 us at 4096 x 1024 x 1024 with bias + dropout + residual, 22.3 vs 19.8 plain,
+  // and the token-step GEMMs of the incremental decoder slower too -- dropped.)
   auto run = [&](auto kind) {
 #pragma unroll 4
     for (int i = 0; i < GROUPS; ++i) {
@@ -1095,9 +1113,12 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
     // at 480 x 1024 x 1024; those launches sit on their fixed costs, not on the depth of the ring.)
     int ns = TM == 1 && splits == 1 && blocks <= 448 ? 4 : 2;
     if (force_ns) ns = TM == 1 ? (force_ns >= 4 ? 4 : 2) : 2;
-    // eight waves per 128 x 128 tile (gemm_glds8_kernel) when a CU gets at most one tile: BMHRL_GEMM_W8 = 0 off, 1 (default) on
-    // for grids of up to W8_MAX workgroups, 2 always
-    static const int w8 = getenv("BMHRL_GEMM_W8") ? atoi(getenv("BMHRL_GEMM_W8")) : 1;
+    // eight waves per 128 x 128 tile (gemm_glds8_kernel) when a CU gets at most one tile: BMHRL_GEMM_W8 = 0 (default) off, 1 on for
+    // grids of up to W8_MAX workgroups, 2 always.  Alone it is the faster kernel on exactly those shapes (4096 x 1024 x 3072 dX
+    // 45.0 -> 38.3 us, 4096 x 1024 x 1024 19.8 -> 18.8 us); inside the captured step, where the audio branch's kernels run beside
+    // these GEMMs, the step measured 5.24 ms with it against 5.02 ms without: its 512-thread workgroups with 96 KiB of LDS leave
+    // a CU no room for a workgroup of the other stream, which is worth more than the kernel's own time.  Off by default.
+    static const int w8 = getenv("BMHRL_GEMM_W8") ? atoi(getenv("BMHRL_GEMM_W8")) : 0;
     static const long w8_max = getenv("BMHRL_GEMM_W8MAX") ? atol(getenv("BMHRL_GEMM_W8MAX")) : 256;
     if constexpr (TM == 2 && TN == 2) {
       if (w8 && splits == 1 && a.K >= 2 * BK && (w8 == 2 || blocks <= w8_max)) {
@@ -1217,7 +1238,9 @@ __global__ __launch_bounds__(1024) void colsum_ordered_kernel(const GemmArgs p, 
 }
 
 // Second pass of the ordered K split: C = [C +] alpha * sum_s slab_s (+ bias) (+ residual), slabs added in split order.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, int batch) {
+// (n_live: the splits that got at least one k-tile -- ceil(k-tiles / splits) tiles each, so the last ones can be empty and
+// their slabs unwritten)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, int batch, int n_live) {
   const long per = (long)p.M * p.N, total = per * batch;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long bz = i / per, r = i - bz * per;
@@ -1225,7 +1248,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p, in
     const int b1 = (int)(bz / p.batch2), b2 = (int)(bz % p.batch2);
     const float* slab = p.split_ws + bz * p.splits * per + r;
     float x = 0.f;
-    for (int sidx = 0; sidx < p.splits; ++sidx) x += slab[sidx * per];
+    for (int sidx = 0; sidx < n_live; ++sidx) x += slab[sidx * per];
     x *= p.alpha;
     if (p.bias) x += p.bias[b1 * p.bias_sb1 + b2 * p.bias_sb2 + n];
     if (p.residual) x += p.residual[b1 * p.r_sb1 + b2 * p.r_sb2 + (long)m * p.ldr + n];
@@ -1334,8 +1357,11 @@ extern "C" int bmhrl_gemm(const bmhrl_gemm_desc* d, bmhrl_stream_t stream) {
   if (e == hipSuccess && a.split_ws) {
     GemmArgs r = a;
     r.splits = tp.splits;
+    const int ktiles = (a.K + BK - 1) / BK, tiles_per_split = (ktiles + tp.splits - 1) / tp.splits;
+    const int n_live = (ktiles + tiles_per_split - 1) / tiles_per_split;
     const long total = (long)batch * a.M * a.N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, r, batch);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, r, batch,
+                       n_live);
     e = hipGetLastError();
   }
   gemm_trace_dump(a, (hipStream_t)stream);

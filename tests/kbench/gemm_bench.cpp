@@ -82,6 +82,11 @@ static void make(const Shape& s, Run& r, unsigned seed) {
 }
 static void release(Run& r) { (void)hipFree(r.dA); (void)hipFree(r.dB); (void)hipFree(r.dC); (void)hipFree(r.dCb); }
 
+// `one` mode: the epilogue of the residual blocks (out-projection / second feed-forward product): fp32 C = dropout(acc + bias) + residual
+static int g_epi = 0;                  // 0 plain, 1 bias + dropout 0.1 + residual, 2 the same + a bf16 copy of the output
+static float *g_bias = nullptr, *g_res = nullptr;
+static uint16_t* g_cb = nullptr;
+
 static int launch(const Shape& s, const Run& r, hipStream_t st) {
   bmhrl_gemm_desc d;
   memset(&d, 0, sizeof d);
@@ -92,6 +97,10 @@ static int launch(const Shape& s, const Run& r, hipStream_t st) {
   d.Cb = r.dCb; d.ldcb = s.N; d.cb_sb1 = (long)s.M * s.N;
   d.epilogue = BMHRL_EPI_LINEAR; d.alpha = 1.f;
   d.allow_split_k = s.split;
+  if (g_epi && !s.out_bf16) {
+    d.bias = g_bias; d.residual = g_res; d.ldr = s.N; d.r_sb1 = (long)s.M * s.N; d.dropout_p = 0.1f; d.seed = 77;
+    if (g_epi == 2) { d.Cb = g_cb; d.ldcb = s.N; d.cb_sb1 = (long)s.M * s.N; }
+  }
   return bmhrl_gemm(&d, st);
 }
 
@@ -218,14 +227,21 @@ int main(int argc, char** argv) {
   if (mode == "one" && argc >= 9) {      // one M N K at bt nb out_bf16 [iters]   (with the trace build: BMHRL_GEMM_TRACE=1 prints stamps)
     Shape s{atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), 0, "one"};
     const int iters = argc > 9 ? atoi(argv[9]) : 20;
+    g_epi = argc > 10 ? atoi(argv[10]) : 0;
     Run r;
     make(s, r, 5u);
+    if (g_epi) {
+      const size_t n = (size_t)s.nb * s.M * s.N;
+      CK(hipMalloc(&g_bias, (size_t)s.N * 4)); CK(hipMemset(g_bias, 0, (size_t)s.N * 4));
+      CK(hipMalloc(&g_res, n * 4)); CK(hipMemset(g_res, 0, n * 4));
+      CK(hipMalloc(&g_cb, n * 2));
+    }
     if (launch(s, r, 0) != 0) { printf("launch failed\n"); return 1; }
     CK(hipDeviceSynchronize());
     const double us = time_shape(s, r, iters);
     const double gf = 2.0 * s.M * s.N * (double)s.K * s.nb / 1e9;
-    printf("M=%d N=%d K=%d at=%d bt=%d nb=%d %s %8.1f us %7.1f TF/s\n", s.M, s.N, s.K, s.at, s.bt, s.nb, s.out_bf16 ? "bf16" : "f32 ", us,
-           gf / us * 1e3);
+    printf("M=%d N=%d K=%d at=%d bt=%d nb=%d %s epi%d %8.1f us %7.1f TF/s\n", s.M, s.N, s.K, s.at, s.bt, s.nb, s.out_bf16 ? "bf16" : "f32 ",
+           g_epi, us, gf / us * 1e3);
     release(r);
     return 0;
   }

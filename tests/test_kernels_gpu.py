@@ -56,6 +56,69 @@ def test_gemm_layouts(dev, M, N, K, a_trans, b_trans):
     assert float(outb[:, N:].float().abs().max()) == 0 if outb.shape[1] > N else True
 
 
+def test_gemm_ordered_k_split(dev):
+    """bmhrl_gemm_desc.split_ws: a K split sums its partial tiles in split order (second launch) instead of fp32 atomics --
+    the d cat[x, goal] product of the vocabulary head (480 x 364 over K = 10 172) and a batched pair product: same values as the
+    atomic form up to the order of fp32 additions, bit-identical from launch to launch, `accumulate` allowed, C not zeroed."""
+    from bmhrl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for (M, N, K, batch) in ((480, 364, 10176, 1), (480, 300, 1024, 2)):
+        splits = ops.gemm_splits(M, N, K, batch)
+        assert splits > 1
+        A = bf(torch.randn(batch, M, K, generator=g)).to(dev)
+        Bm = bf(torch.randn(batch, K, N, generator=g)).to(dev)
+        ref = torch.einsum("bmk,bkn->bmn", A.float(), Bm.float())
+        As, Bs = padded(A), padded(Bm)
+        kw = dict(lda=As.shape[-1], ldb=Bs.shape[-1], b_trans=True, batch=(1, batch), a_strides=(0, M * As.shape[-1]),
+                  b_strides=(0, K * Bs.shape[-1]), ldc=N, c_strides=(0, M * N), allow_split_k=True)
+        atom = torch.zeros(batch, M, N, device=dev)
+        ops.gemm(As, Bs, M, N, K, C_f32=atom, **kw)
+        ws = torch.full((splits * batch * M * N,), float("nan"), device=dev)
+        outs = []
+        for _ in range(3):
+            out = torch.full((batch, M, N), float("nan"), device=dev)          # (never zeroed: every element is stored)
+            ops.gemm(As, Bs, M, N, K, C_f32=out, split_ws=ws, **kw)
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert rel_err(outs[0], ref) < 2e-5 and rel_err(outs[0], atom) < 2e-6
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        acc = torch.ones(batch, M, N, device=dev)
+        ops.gemm(As, Bs, M, N, K, C_f32=acc, split_ws=ws, accumulate=True, alpha=0.5, **kw)
+        assert rel_err(acc, 1 + 0.5 * ref) < 2e-5
+        # a workspace that is too small is refused for `accumulate` (atomics cannot accumulate into a live C) and ignored otherwise
+        small = torch.zeros(8, device=dev)
+        out = torch.zeros(batch, M, N, device=dev)
+        ops.gemm(As, Bs, M, N, K, C_f32=out, split_ws=small, **kw)
+        assert rel_err(out, ref) < 2e-5
+        with pytest.raises(RuntimeError):
+            ops.gemm(As, Bs, M, N, K, C_f32=acc, split_ws=small, accumulate=True, **kw)
+
+
+def test_expand_goals_backward_is_ordered(dev):
+    """bmhrl_scatter_add_rows along an expand_goals row map: every row of dx written, sums in row order (bit-identical runs)"""
+    from bmhrl_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, L, D = 7, 30, 64
+    seg = (torch.rand(B, L, generator=g) < 0.25).to(torch.int32).to(dev)
+    seg[3] = 0
+    src = torch.empty(B * L, dtype=torch.int32, device=dev)
+    ops.expand_goals_index(seg, src, B, L)
+    dout = torch.randn(B * L, D, generator=g).to(dev)
+    want = torch.zeros(B * L, D, dtype=torch.float64)
+    s_cpu, d_cpu = src.cpu(), dout.cpu().double()
+    for r in range(B * L):
+        if int(s_cpu[r]) >= 0:
+            want[int(s_cpu[r])] += d_cpu[r]
+    runs = []
+    for _ in range(2):
+        dx = torch.full((B * L, D), float("nan"), device=dev)
+        ops.scatter_add_rows(dout, src, dx, B * L, D)
+        runs.append(dx)
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0], runs[1])
+    assert float((runs[0].cpu().double() - want).abs().max()) < 1e-5
+
+
 def test_gemm_linear_epilogue(dev):
     from bmhrl_amd import ops
     g = torch.Generator().manual_seed(1)

@@ -51,12 +51,19 @@ def test_parallel_branches_do_not_change_results():
     p1, s1, l1, g1 = _run(True)
     assert torch.equal(s0, s1) and torch.equal(p0, p1) and l0 == l1
     assert g0.keys() == g1.keys() and len(g0) > 100
-    # Default mode: sums that go through fp32 atomics (split-K products -- since r03 also two dX products, so the order noise
-    # reaches the activation gradients and, through a bf16 rounding that flips, shows as ~1e-3 on the cancellation-prone
-    # key / query weights of the first encoder layer) depend on the arrival order in ANY run, serial or not: here only a
-    # coarse bound; the exact statement is the deterministic-mode test below.
+    # Default mode (r04): nothing on the ACTIVATION path sums through fp32 atomics any more -- the K-split dX products add their
+    # partial tiles in split order (bmhrl_gemm_desc.split_ws), the expand_goals backward adds in row order --, so every gradient
+    # that is produced by a store (the large projections' weight gradients, which is where r03 saw 1e-3 on the first encoder
+    # layer's key / query weights) is bit-identical with and without the side streams.  Leaf sums that still use atomics (K-split
+    # weight gradients of the 480-row caption side, bias / LayerNorm column sums, the embedding scatter) differ by the order of
+    # their fp32 additions only: 1e-5 of the tensor's norm bounds them.
     worst = max(float((g0[k] - g1[k]).norm() / (g0[k].norm() + 1e-6 * g0[k].numel() ** 0.5)) for k in g0)
-    assert worst < 5e-3, worst
+    assert worst < 1e-5, worst
+    for k in ("bm_enc.encoder.layers.0.self_att_M1.linear_Q2d.weight", "bm_enc.encoder.layers.0.self_att_M1.linear_K2d.weight",
+              "bm_enc.encoder.layers.0.bi_modal_att_M2.linear_Q2d.weight", "bm_enc.encoder.layers.1.feed_forward_M1.fc1.weight",
+              "bm_enc.encoder.layers.0.feed_forward_M2.fc2.weight"):
+        assert torch.equal(g0[k], g1[k]), k
+    assert sum(torch.equal(g0[k], g1[k]) for k in g0) >= len(g0) // 3
 
 
 _DET_STREAMS = r"""
