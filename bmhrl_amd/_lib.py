@@ -95,6 +95,10 @@ PROTOTYPES = {
     "bmhrl_gather_rows": [ptr, ptr, ptr, ptr, i64, i64, i32, ptr],
     "bmhrl_expand_goals": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, ptr],
     "bmhrl_expand_goals_explore": [ptr, ptr, ptr, ptr, ptr, i64, i32, i32, i32, f32, f32, u64, ptr, ptr, ptr],
+    "bmhrl_unfold1d_bf16": [ptr, ptr, i64, i32, i32, i32, i32, i32, ptr],
+    "bmhrl_fold1d": [ptr, i64, ptr, i32, i32, i32, i32, i32, ptr],
+    "bmhrl_groupnorm_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, f32, ptr],
+    "bmhrl_groupnorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, ptr],
     "bmhrl_scatter_add_rows": [ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_log_softmax": [ptr, i64, i64, i32, ptr],
     "bmhrl_smooth_kl_fwd": [ptr, i64, ptr, ptr, ptr, ptr, f32, i32, i32, ptr, ptr, i64, i32, ptr],

@@ -664,9 +664,29 @@ __global__ __launch_bounds__(256) void expand_goals_kernel(const int32_t* __rest
   __shared__ float red[16];
   const int b = blockIdx.x;
   if constexpr (EXPLORE) {
+    // (16-byte loads, eight of them in flight per thread: the first form -- one dependent 4-byte load per element and pass --
+    // took 50 us on the caption-side chain of the captured step for the 120 KB of the reference's goals)
     const long total = (long)B * L * D;
+    const bool v4 = (total & 3) == 0 && ((uintptr_t)x & 15) == 0;
+    const long n4 = v4 ? total >> 2 : 0;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
     float s = 0.f, cnt = 0.f;
-    for (long i = threadIdx.x; i < total; i += 256) {
+    for (long i0 = threadIdx.x; i0 < n4; i0 += 8 * 256) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long i = i0 + u * 256;
+        t[u] = i < n4 ? x4[i] : f32x4{NAN, NAN, NAN, NAN};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = t[u][e];
+          if (v == v) { s += v; cnt += 1.f; }
+        }
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < total; i += 256) {
       const float v = x[i];
       if (v == v) { s += v; cnt += 1.f; }
     }
@@ -674,7 +694,22 @@ __global__ __launch_bounds__(256) void expand_goals_kernel(const int32_t* __rest
     cnt = block_sum(cnt, red);                 // (exact below 2^24 elements per thread stride; the goals are B L 64)
     const float mean = s / cnt;                // all-NaN input: NaN, as torch.nanmean
     float sq = 0.f;
-    for (long i = threadIdx.x; i < total; i += 256) {
+    for (long i0 = threadIdx.x; i0 < n4; i0 += 8 * 256) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long i = i0 + u * 256;
+        t[u] = i < n4 ? x4[i] : f32x4{NAN, NAN, NAN, NAN};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = t[u][e];
+          if (v == v) sq += (v - mean) * (v - mean);
+        }
+    }
+    for (long i = 4 * n4 + threadIdx.x; i < total; i += 256) {
       const float v = x[i];
       if (v == v) sq += (v - mean) * (v - mean);
     }
@@ -1556,4 +1591,4 @@ extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 //     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce, bmhrl_fusion_tail_fwd / _bwd
 // 11: bmhrl_batch_head, bmhrl_smooth_kl_bwd loss_scale2, bmhrl_layernorm_fwd_groups / _bwd_groups, bmhrl_colsum_bf16_groups,
 //     bmhrl_cast_bf16_copies
-extern "C" int bmhrl_hip_abi_version(void) { return 14; }
+extern "C" int bmhrl_hip_abi_version(void) { return 15; }

@@ -1484,6 +1484,89 @@ class LinearFn(torch.autograd.Function):
         return (dx.view(shp) if dx is not None else None), dw, db, None, None
 
 
+class Conv1dSameFn(torch.autograd.Function):
+    """nn.Conv1d(C_in, C_out, k, padding='same') over the time axis of x (B, T, C_in) -> (B, T, C_out) (the reference applies
+    it to the transposed (B, C, T) tensor: model/det_bmhrl_agent.py:79-86,169-174).  A GEMM over the unfolded operand
+    (csrc/conv_gn.hip): rows (b, t), columns (j, c_in); the weight (C_out, C_in, k) is used as (C_out, k * C_in).
+    'same' padding: k - 1 zeros in total, (k - 1) // 2 of them in front."""
+
+    @staticmethod
+    def _operand(w):
+        co, ci, k = w.shape
+        w2 = w.detach().permute(0, 2, 1).reshape(co, k * ci)           # [c_out][j * C_in + c_in]
+        wb = ops.bf16_zeros(co, k * ci, w.device)
+        ops.cast_bf16(w2.contiguous(), k * ci, wb, wb.shape[1], co, k * ci)
+        return wb
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, T, C = x.shape
+        co, ci, k = w.shape
+        assert ci == C and C % 4 == 0
+        left = (k - 1) // 2
+        dev = x.device
+        K = k * C
+        unf = ops.bf16_zeros(B * T, K, dev)
+        ops.unfold1d_bf16(x.contiguous(), unf, unf.shape[1], B, T, C, k, left)
+        wb = Conv1dSameFn._operand(w)
+        y = torch.empty(B * T, co, device=dev)
+        ops.gemm(unf, wb, B * T, co, K, lda=unf.shape[1], ldb=wb.shape[1], C_f32=y, ldc=co, bias=None if b is None else b.detach())
+        ctx.save_for_backward(unf, w)
+        ctx.cfg = (B, T, C, co, k, left, b is not None)
+        return y.view(B, T, co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, C, co, k, left, has_b = ctx.cfg
+        unf, w = ctx.saved_tensors
+        dev = dy.device
+        K = k * C
+        need = ctx.needs_input_grad
+        rows = B * T
+        dy2 = dy.contiguous().view(rows, co)
+        dyb, db = _cast_dy(dy2, rows, co, 0.0, 0, has_b and need[2])
+        dx = dw = None
+        if need[1]:
+            dw2 = torch.zeros(co, K, device=dev)
+            ops.gemm(dyb, unf, co, K, rows, lda=dyb.shape[1], ldb=unf.shape[1], a_trans=True, b_trans=True, C_f32=dw2, ldc=K,
+                     allow_split_k=True)
+            dw = dw2.view(co, k, C).permute(0, 2, 1).contiguous()
+        if need[0]:
+            wb = Conv1dSameFn._operand(w)
+            du = torch.empty(rows, K, device=dev)
+            ops.gemm(dyb, wb, rows, K, co, lda=dyb.shape[1], ldb=wb.shape[1], b_trans=True, C_f32=du, ldc=K)
+            dx = torch.empty(B, T, C, device=dev)
+            ops.fold1d(du, K, dx, B, T, C, k, left)
+        return dx, dw, db
+
+
+class GroupNormFn(torch.autograd.Function):
+    """nn.GroupNorm(G, C) of the reference's input projection (model/det_bmhrl_agent.py:83) on x (B, T, C): statistics over
+    the T time steps and C / G channels of a (sample, group)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps):
+        B, T, C = x.shape
+        dev = x.device
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(B * G, device=dev), torch.empty(B * G, device=dev)
+        ops.groupnorm_fwd(x, gamma.detach(), beta.detach(), y, mean, rstd, B, T, C, G, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.cfg = (B, T, C, G)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, C, G = ctx.cfg
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dev = dy.device
+        dx = torch.empty(B, T, C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ops.groupnorm_bwd(dy.contiguous(), x, gamma.detach(), mean, rstd, dx, dg, db, B, T, C, G)
+        return dx, dg, db, None, None
+
+
 class LayerNormFn(torch.autograd.Function):
     """fp32 LayerNorm (normCA / normCV, model/bm_hrl_agent.py:107-108)."""
 

@@ -4,7 +4,7 @@
     import bmhrl_amd.install  # before `from model.bm_hrl_agent import BMHrlAgent`
 
 Only the hot-path modules are aliased (model.bm_hrl_agent, model.blocks, model.multihead_attention, model.masking,
-model.encoder, model.decoder, model.utils,
+model.encoder, model.decoder, model.utils, model.det_bmhrl_agent, model.object_detector,
 loss.label_smoothing, loss.biased_kl, epoch_loops.captioning_bmrl_loops, epoch_loops.validation_loops,
 captioning_datasets.load_features); everything
 else keeps resolving to the reference's own files."""
@@ -20,6 +20,8 @@ ALIASES = {
     "model.encoder": "bmhrl_amd.model.encoder",
     "model.decoder": "bmhrl_amd.model.decoder",
     "model.utils": "bmhrl_amd.model.utils",
+    "model.det_bmhrl_agent": "bmhrl_amd.model.det_bmhrl_agent",
+    "model.object_detector": "bmhrl_amd.model.object_detector",
     "loss.label_smoothing": "bmhrl_amd.loss.label_smoothing",
     "loss.biased_kl": "bmhrl_amd.loss.biased_kl",
     "epoch_loops.captioning_bmrl_loops": "bmhrl_amd.epoch_loops.captioning_bmrl_loops",

@@ -589,3 +589,28 @@ def batch_head(rgb, audio, captions, pad_idx, copies=1, bump64=None, bump32=()):
                                             cm.data_ptr(), trg_in.data_ptr(), trg_y.data_ptr(), _p(bump64), _p(b32[0]), _p(b32[1]),
                                             stream()), "bmhrl_batch_head")
     return vm, am, cm, trg_in, trg_y
+
+
+# ---- Conv1d('same') + GroupNorm input projection of the DETR-mode agent (csrc/conv_gn.hip)
+def unfold1d_bf16(x, out, ldo, B, T, C, k, left):
+    """out[(b, t)][j * C + c] = x[b][t + j - left][c] (0 outside the clip), bf16: the operand of a Conv1d as a GEMM"""
+    _need_cuda(x, out)
+    _lib.check(_lib.load().bmhrl_unfold1d_bf16(x.data_ptr(), out.data_ptr(), ldo, B, T, C, k, left, stream()), "bmhrl_unfold1d_bf16")
+
+
+def fold1d(du, ldu, dx, B, T, C, k, left):
+    """dx[b][t][c] = sum_j du[(b, t - j + left)][j * C + c]: the data gradient of the unfolded operand"""
+    _need_cuda(du, dx)
+    _lib.check(_lib.load().bmhrl_fold1d(du.data_ptr(), ldu, dx.data_ptr(), B, T, C, k, left, stream()), "bmhrl_fold1d")
+
+
+def groupnorm_fwd(x, gamma, beta, y, mean, rstd, B, T, C, G, eps):
+    _need_cuda(x, y)
+    _lib.check(_lib.load().bmhrl_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), B, T, C, G, float(eps), stream()), "bmhrl_groupnorm_fwd")
+
+
+def groupnorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, B, T, C, G):
+    _need_cuda(dy, x, dx)
+    _lib.check(_lib.load().bmhrl_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dx.data_ptr(), _p(dgamma), _p(dbeta), B, T, C, G, stream()), "bmhrl_groupnorm_bwd")

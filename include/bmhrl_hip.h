@@ -477,6 +477,23 @@ int bmhrl_batch_head(const float* rgb, int64_t ld_rgb, const float* audio, int64
 
 /* Library self-description: returns the gfx target the kernels were built for ("gfx950"). */
 const char* bmhrl_hip_arch(void);
+/* ---------------------------------------------------------------------------------------------
+ * Conv1d(padding='same') + GroupNorm input projection of the DETR-mode agent (model/det_bmhrl_agent.py:79-86,169-174),
+ * activations (B, T, C) row major.  The convolution itself is bmhrl_gemm over the unfolded operand:
+ *   bmhrl_unfold1d_bf16: out[(b, t)][j*C + c] = x[b][t + j - left][c] (0 outside the clip), bf16; 'same' padding: left = (k-1)/2
+ *   bmhrl_fold1d:        dx[b][t][c] = sum_j dU[(b, t - j + left)][j*C + c]      (the data gradient; ordered, no atomics)
+ *   bmhrl_groupnorm_fwd / _bwd: nn.GroupNorm(G, C) over (T, C/G) per sample and group; mean / rstd (B*G) saved for the
+ *   backward; dgamma / dbeta are ADDED to (zero them first).
+ * ------------------------------------------------------------------------------------------- */
+int bmhrl_unfold1d_bf16(const float* x, void* out, int64_t ldo, int32_t B, int32_t T, int32_t C, int32_t k, int32_t left,
+                        bmhrl_stream_t stream);
+int bmhrl_fold1d(const float* du, int64_t ldu, float* dx, int32_t B, int32_t T, int32_t C, int32_t k, int32_t left,
+                 bmhrl_stream_t stream);
+int bmhrl_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t B,
+                        int32_t T, int32_t C, int32_t G, float eps, bmhrl_stream_t stream);
+int bmhrl_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                        float* dgamma, float* dbeta, int32_t B, int32_t T, int32_t C, int32_t G, bmhrl_stream_t stream);
+
 int bmhrl_hip_abi_version(void);
 
 #ifdef __cplusplus

@@ -501,6 +501,53 @@ def detr_stack(sd: SD, p: str, n_layers: int, x: Tensor, layer_fn, has_norm: boo
     return torch.stack(inter) if return_intermediate else x
 
 
+def conv1d_same_groupnorm(sd: SD, p: str, x: Tensor, groups: int = 32) -> Tensor:
+    """One block of DetrCaption.input_proj, model/det_bmhrl_agent.py:79-86 applied at :169-174: Conv1d(C, C, k,
+    padding='same') over the time axis of x (B, T, C) followed by GroupNorm(groups, C) (eps 1e-5); `p` = "input_proj.i".
+    'same' padding: k - 1 zeros in total, (k - 1) // 2 in front (the extra one of an even kernel goes behind)."""
+    w, b = sd[p + ".0.weight"], sd[p + ".0.bias"]
+    k = w.shape[-1]
+    left = (k - 1) // 2
+    xt = torch.nn.functional.pad(x.transpose(1, 2), (left, k - 1 - left))
+    y = torch.nn.functional.conv1d(xt, w, b)
+    y = torch.nn.functional.group_norm(y, groups, sd[p + ".1.weight"], sd[p + ".1.bias"], 1e-5)
+    return y.transpose(1, 2)
+
+
+def object_detect(sd: SD, p: str, x: Tensor, mask: Tensor, voc_size: int):
+    """ObjectDetect.forward, model/object_detector.py:33-46: 256-wide projection, 6 post-norm encoder layers (H = 4), 6 decoder
+    layers over 100 learned queries (tgt = 0, query positions added: add_pos=True), class logits, the detached query states and
+    the "no object" mask (arg-max class == voc_size)."""
+    src = linear(sd, p + ".input_projection", x)
+    memory = detr_stack(sd, p + ".encoder", 6, src, lambda q, t: detr_encoder_layer(sd, q, t, mask, 4), True, False)
+    qpos = sd[p + ".query_embed.weight"].unsqueeze(0).repeat(x.shape[0], 1, 1)
+    hs = detr_stack(sd, p + ".decoder", 6, torch.zeros_like(qpos),
+                    lambda q, t: detr_decoder_layer(sd, q, t, memory, mask, qpos, None, None, None, True, None, 4), True, False)
+    logits = linear(sd, p + ".class_embed", hs)
+    return logits, hs.detach(), (logits.argmax(-1) == voc_size).detach()
+
+
+def detr_caption_forward(sd: SD, cfg, x_video: Tensor, trg: Tensor, masks: Dict[str, Tensor]):
+    """DetrCaption.forward with use_manager = False and pre_goal_attention = False, model/det_bmhrl_agent.py:158-208:
+    (log-probs, worker features[..., :300], encoder memory, class logits).  The end token (3) is embedded as padding (1), :161-162;
+    the caption decoder runs causal self attention (add_pos=False) -- the branch the CPU reference cannot execute
+    (model/multihead_attention.py:19) -- and attends the detached object queries without a mask (model/decoder.py:106)."""
+    H, V = cfg.rl_att_heads, sd["linear.weight"].shape[0]
+    trg = trg.clone()
+    trg[trg == 3] = 1
+    C = sd["emb_C.embedder.weight"][trg] * math.sqrt(cfg.d_model_caps)
+    vf = x_video
+    for i in range(3):
+        vf = conv1d_same_groupnorm(sd, f"input_proj.{i}", vf)
+    cls, hs, _ = object_detect(sd, "object_detector", vf, masks["V_mask"], V)
+    memory = detr_stack(sd, "encoder", 3, vf, lambda q, t: detr_encoder_layer(sd, q, t, masks["V_mask"], H), True, False)
+    feat = detr_stack(sd, "worker_decoder", 3, C,
+                      lambda q, t: detr_decoder_layer(sd, q, t, memory, masks["V_mask"], None, masks["C_mask"], None, None, False, hs, H),
+                      True, False)
+    pred = torch.log_softmax(linear(sd, "linear", feat), -1)
+    return pred, feat[:, :, :300], memory, cls
+
+
 # --------------------------------------------------------------------------------------
 # host-side RL glue of the reference (SURVEY.md 8f rank 2), restated as the loops they are
 # discontinue_reward_loop is pinned to the reference's own function (tests/golden/rl_glue.npz: metrics/util.py loads

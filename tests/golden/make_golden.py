@@ -337,6 +337,58 @@ def detr_cases():
     np.savez_compressed(os.path.join(HERE, "detr.npz"), **out)
 
 
+def detr_agent_case():
+    """DetrCaption (model/det_bmhrl_agent.py) at small widths: the state dict of the reference's own module and what its forward
+    produces up to the point the CPU can take it -- the three Conv1d('same') + GroupNorm blocks, the 100-query object detector
+    and the video encoder.  The caption decoder's causal self attention raises on the CPU (get_device() == -1,
+    model/multihead_attention.py:19), so the log-probs are pinned through the oracle (tests/test_oracle_golden.py checks the
+    oracle against everything stored here; tests/golden/detr.npz holds the decoder layer itself).  model/object_detector.py
+    imports torchvision.models.VisionTransformer without using it: an empty module of that name lets the file import."""
+    import types
+    if "torchvision" not in sys.modules:
+        tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+        tvm.VisionTransformer = object
+        tv.models = tvm
+        sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tvm
+    from model.det_bmhrl_agent import DetrCaption
+    V = 41
+    cfg = syn.tiny_cfg(d_model=64, d_model_video=64, d_vid=64, d_model_caps=20, rl_att_heads=4, rl_goal_d=8, dout_p=0.0)
+    cfg.pre_goal_attention = False
+    cfg.device = "cpu"
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "critic.cp")
+        torch.save(syn.synthetic_critic_state(cfg.d_model_caps, seed=1), path)
+        cfg.rl_critic_path = path
+        ds = SimpleNamespace(trg_voc_size=V, train_vocab=SimpleNamespace(vectors=None))
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            agent = DetrCaption(cfg, ds)
+    shapes = {k: tuple(v.shape) for k, v in agent.state_dict().items()}
+    sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=13)
+    sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(cfg.d_model_caps, seed=1).items()})
+    agent.load_state_dict(sd)
+    agent.eval()
+    g = torch.Generator().manual_seed(31)
+    B, T = 2, 11
+    xv = torch.randn(B, T, cfg.d_model, generator=g)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    mask[1, 0, T - 3:] = False
+    # the weights themselves are not stored (27 M values): they are syn.fill_state_dict(shapes, seed=13) + the synthetic critic
+    # (seed 1), a pure function of the names and shapes recorded here -- which also pin the module's state-dict layout
+    keys = sorted(agent.state_dict().keys())
+    out = {"keys": np.array(keys), "shapes": np.array([",".join(str(d) for d in shapes[k]) for k in keys])}
+    out["x_video"], out["V_mask"] = np_(xv), np_(mask)
+    with torch.no_grad():
+        vf = xv.transpose(1, 2)
+        for i in range(agent.n_time):
+            vf = agent.input_proj[i](vf)
+            out[f"proj{i}"] = np_(vf.transpose(1, 2))
+        xp = vf.transpose(1, 2)
+        cls, hs, ob_mask = agent.object_detector(xp, mask)
+        out["obj_logits"], out["obj_hs"], out["obj_mask"] = np_(cls), np_(hs), np_(ob_mask)
+        out["memory"] = np_(agent.encoder(xp, mask, agent.pos_enc))
+    np.savez_compressed(os.path.join(HERE, "detr_agent.npz"), **out)
+
+
 def rl_glue_cases():
     """metrics/util.py:discontinue_reward (the file imports only torch, so it is loaded by path; its package pulls nltk).
     The segment loops of metrics/batched_meteor.py and epoch_loops/captioning_bmrl_loops.py are run by rl_loops_cases()."""
@@ -569,6 +621,9 @@ if __name__ == "__main__":
     if "--only-rl-loops" in sys.argv:
         rl_loops_cases()
         sys.exit(0)
+    if "--only-detr-agent" in sys.argv:
+        detr_agent_case()
+        sys.exit(0)
     if "--only-bkl" in sys.argv:
         biased_kl_forward_cases()
         sys.exit(0)
@@ -583,6 +638,7 @@ if __name__ == "__main__":
     agent_tiny()
     sample_clip_decode()
     detr_cases()
+    detr_agent_case()
     rl_glue_cases()
     rl_loops_cases()
     loader_cases()

@@ -191,3 +191,24 @@ def test_bench_refuses_to_report_fewer_gpus_than_asked():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0          # (no GPU here; on a GPU box: "--gpus 2 but WORLD_SIZE=1")
+
+
+def test_detr_agent_checkpoint_layout_matches_the_reference():
+    """DetrCaption (model/det_bmhrl_agent.py) builds without a GPU and has the reference module's state-dict keys and shapes
+    (recorded from the reference's own module in tests/golden/detr_agent.npz); the driver's import resolves"""
+    import os
+    from types import SimpleNamespace
+    import numpy as np
+    import bmhrl_amd.install  # noqa: F401
+    from model.det_bmhrl_agent import DetrCaption
+    from bmhrl_amd import synthetic as syn
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detr_agent.npz"), allow_pickle=False))
+    cfg = syn.tiny_cfg(d_model=64, d_model_video=64, d_vid=64, d_model_caps=20, rl_att_heads=4, rl_goal_d=8, dout_p=0.0)
+    cfg.pre_goal_attention = False
+    agent = DetrCaption(cfg, SimpleNamespace(trg_voc_size=41, train_vocab=SimpleNamespace(vectors=None)))
+    want = {str(k): tuple(int(d) for d in str(s).split(",") if d != "") for k, s in zip(g["keys"], g["shapes"])}
+    assert {k: tuple(v.shape) for k, v in agent.state_dict().items()} == want
+    assert agent.name == "detr_agent" and agent.manager.exploration
+    agent.teach_worker()
+    assert not agent.manager.exploration and all(p.requires_grad for p in agent.linear.parameters())
+    assert not any(p.requires_grad for p in agent.manager_decoder.parameters())

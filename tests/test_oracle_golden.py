@@ -281,3 +281,29 @@ def test_biased_kl_forward_amplitude_is_an_argument(golden, tag):
     (div.sum(-1) * T("up")).sum().backward()
     assert torch.allclose(div.sum(-1).detach(), T(f"{tag}_rows"), atol=1e-6)
     assert torch.allclose(x.grad, T(f"{tag}_grad_logits"), atol=1e-6)
+
+
+def _detr_agent_state(g):
+    keys = [str(k) for k in g["keys"]]
+    shapes = {k: tuple(int(d) for d in str(s).split(",") if d != "") for k, s in zip(keys, g["shapes"])}
+    sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=13)
+    sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(20, seed=1).items()})
+    return sd, shapes
+
+
+def test_detr_agent_input_projection_object_detector_and_encoder(golden):
+    """oracle.conv1d_same_groupnorm / object_detect / the post-norm encoder stack against the reference's own DetrCaption
+    (tests/golden/detr_agent.npz, model/det_bmhrl_agent.py:169-176 + model/object_detector.py:33-46)"""
+    g = golden("detr_agent")
+    sd, _ = _detr_agent_state(g)
+    x, mask = torch.from_numpy(g["x_video"]), torch.from_numpy(g["V_mask"])
+    vf = x
+    for i in range(3):
+        vf = O.conv1d_same_groupnorm(sd, f"input_proj.{i}", vf)
+        assert torch.allclose(vf, torch.from_numpy(g[f"proj{i}"]), atol=2e-5), i
+    logits, hs, ob_mask = O.object_detect(sd, "object_detector", vf, mask, 41)
+    assert torch.allclose(hs, torch.from_numpy(g["obj_hs"]), atol=1e-4)
+    assert torch.allclose(logits, torch.from_numpy(g["obj_logits"]), atol=1e-4)
+    assert torch.equal(ob_mask, torch.from_numpy(g["obj_mask"]))
+    mem = O.detr_stack(sd, "encoder", 3, vf, lambda q, t: O.detr_encoder_layer(sd, q, t, mask, 4), True, False)
+    assert torch.allclose(mem, torch.from_numpy(g["memory"]), atol=1e-4)
