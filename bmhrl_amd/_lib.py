@@ -71,6 +71,9 @@ PROTOTYPES = {
     "bmhrl_softmax_rows": [ptr, i64, ptr, i64, i64, i32, i32, i64, ptr],
     "bmhrl_softmax_bwd_rows": [ptr, i64, ptr, i64, ptr, i64, i64, i32, f32, ptr, i64, i64, i32, i32, i32, i64, ptr],
     "bmhrl_attn_delta": [ptr, i64, ptr, i64, ptr, f32, i32, i32, i32, i32, ptr],
+    "bmhrl_attention_bwd_scores256_ok": [i32, i32, i32, i64],
+    "bmhrl_attention_bwd_scores256": [ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, i32, i32, i32, i32,
+                                      f32, ptr],
     "bmhrl_layernorm_fwd": [ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_layernorm_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr],
     "bmhrl_layernorm_bwd_ws": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, i32, ptr, i64, ptr],

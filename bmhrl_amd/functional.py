@@ -410,6 +410,8 @@ def _use_flash(dk: int, Sq: int, Sk: int) -> bool:
 # the video side (44 vs 35 us), so off by default
 FUSED_MEMATTN = os.environ.get("BMHRL_FUSED_MEMATTN", "0") == "1"
 SMALL_ATTN = os.environ.get("BMHRL_SMALL_ATTN", "1") == "1"      # one-launch attention core for Sq, Sk <= 32 (A/B switch)
+# P / delta / dS of the head-dimension-256 attentions with <= 256 keys in one launch (csrc/attention_bwd256.hip; A/B switch)
+FUSED_SCORES_BWD = os.environ.get("BMHRL_FUSED_SCORES_BWD", "1") == "1"
 
 
 def _use_small(dk, Sq, Sk, *lds_and_offs) -> bool:
@@ -487,10 +489,21 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     D = H * dk
     scale = 1.0 / math.sqrt(dk)
     Skp = pad8(Sk)
+    pstr = (H * Sq * Skp, Sq * Skp)
+    fused = (FUSED_SCORES_BWD and stats[0] == "flash" and ops.attention_bwd_scores256_ok(Sq, Sk, dk, msq)
+             and all(v % 8 == 0 for v in (ldq, ldk, ldv, q_off, k_off, v_off)))
+    if fused:
+        # at most 256 keys: P, the row term and dS in one launch, the whole score row of a query on one lane
+        P = torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)
+        dS = torch.empty(B, H, Sq, Skp, dtype=_BF16, device=dev)
+        ops.attention_bwd_scores256(Qb, ldq, Kb, ldk, Vb, ldv, dOb, D, stats[1], stats[2], mask, msb, P, dS, Skp, B, H, Sq, Sk,
+                                    scale, q_off=q_off, k_off=k_off, v_off=v_off)
+        _attn_grad_products(P, dS, pstr, dOb, Qb, q_off, ldq, Kb, k_off, ldk, dQb, dq_off, lddq, dKb, dk_off, lddk, dVb, dv_off,
+                            lddv, B, H, Sq, Sk, dk, Skp, csq, csk, csv)
+        return
     delta = torch.empty(B, H, Sq, device=dev)
     # sum_d dO_pre * O_pre == (1-p) * sum_d dO_pre * O_post   (both carry the same keep mask / scale)
     ops.attn_delta(dOb, D, Ob, D, delta, B, H, Sq, dk, scale=1.0 - p_drop)
-    pstr = (H * Sq * Skp, Sq * Skp)
     if stats[0] == "flash":
         P = _padded_bf16(B * H * Sq, Sk, dev).view(B, H, Sq, Skp)
         ops.gemm(Qb, Kb, Sq, Sk, dk, lda=ldq, ldb=ldk, a_off=q_off, b_off=k_off, batch=(B, H), a_strides=(Sq * ldq, dk),
@@ -502,7 +515,14 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     ops.gemm(dOb, Vb, Sq, Sk, dk, lda=D, ldb=ldv, b_off=v_off, batch=(B, H), a_strides=(Sq * D, dk),
              b_strides=(Sk * ldv, dk), C_bf16=dS, ldcb=Skp, cb_strides=pstr, epilogue=ops.EPI_DSCORE, alpha=scale,
              rowvec=delta, rv_strides=(H * Sq, Sq), aux=P, ldaux=Skp, aux_strides=pstr, mask=mask, mask_sb1=msb, mask_sm=msq)
-    # dV = P^T dO ; dK = dS^T Q ; dQ = dS K
+    _attn_grad_products(P, dS, pstr, dOb, Qb, q_off, ldq, Kb, k_off, ldk, dQb, dq_off, lddq, dKb, dk_off, lddk, dVb, dv_off, lddv,
+                        B, H, Sq, Sk, dk, Skp, csq, csk, csv)
+
+
+def _attn_grad_products(P, dS, pstr, dOb, Qb, q_off, ldq, Kb, k_off, ldk, dQb, dq_off, lddq, dKb, dk_off, lddk, dVb, dv_off, lddv,
+                        B, H, Sq, Sk, dk, Skp, csq, csk, csv):
+    """dV = P^T dO ; dK = dS^T Q ; dQ = dS K (bf16 into column slices; cs*: fused column sums for the projection biases)"""
+    D = H * dk
     ops.gemm(P, dOb, Sk, dk, Sq, lda=Skp, ldb=D, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,
              b_strides=(Sq * D, dk), C_bf16=dVb, ldcb=lddv, cb_off=dv_off, cb_strides=(Sk * lddv, dk), **csv)
     ops.gemm(dS, Qb, Sk, dk, Sq, lda=Skp, ldb=ldq, b_off=q_off, a_trans=True, b_trans=True, batch=(B, H), a_strides=pstr,

@@ -234,6 +234,21 @@ def attn_delta(dO, lddo, O, ldo, delta, B, H, Sq, dk, scale=1.0):
                "bmhrl_attn_delta")
 
 
+def attention_bwd_scores256_ok(Sq, Sk, dk, msq):
+    return bool(_lib.load().bmhrl_attention_bwd_scores256_ok(Sq, Sk, dk, msq))
+
+
+def attention_bwd_scores256(Q, ldq, K, ldk, V, ldv, dO, lddo, row_max, row_sum, mask, msb, P, dS, ldp, B, H, Sq, Sk, scale,
+                            q_off=0, k_off=0, v_off=0):
+    """P and dS (bf16 (B, H, Sq, ldp)) of a head-dimension-256 attention with at most 256 keys from the forward's statistics:
+    one launch (csrc/attention_bwd256.hip); offsets in elements"""
+    _need_cuda(Q)
+    _lib.check(_lib.load().bmhrl_attention_bwd_scores256(Q.data_ptr() + 2 * q_off, ldq, K.data_ptr() + 2 * k_off, ldk,
+                                                         V.data_ptr() + 2 * v_off, ldv, dO.data_ptr(), lddo, row_max.data_ptr(),
+                                                         row_sum.data_ptr(), _p(mask), msb, P.data_ptr(), dS.data_ptr(), ldp, B, H,
+                                                         Sq, Sk, scale, stream()), "bmhrl_attention_bwd_scores256")
+
+
 def layernorm_fwd(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows, D):
     _need_cuda(x)
     _lib.check(_lib.load().bmhrl_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(y_bf16), ldy, _p(y_f32),

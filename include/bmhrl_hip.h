@@ -193,6 +193,19 @@ int bmhrl_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t 
                            int32_t rows_per_query, int32_t queries, int32_t rows_per_group, int64_t group_stride,
                            bmhrl_stream_t stream);
 
+/* Softmax part of the backward of the head-dimension-256 attentions with at most 256 keys (video self attention, A<-V cross
+ * attention: autograd of attention(), model/multihead_attention.py:7-31, called at model/bm_hrl_agent.py:358-377) in ONE
+ * launch: P = exp(masked scaled scores - row_max) / row_sum from the forward's statistics, dP = dO V^T,
+ * delta = sum_k P dP, dS = P (dP - delta) scale (0 at masked keys: no gradient through masked_fill).  Q, K, V, dO are bf16
+ * rows with head h at columns [h*256, h*256+256) (leading dims in elements); mask: key mask (B, Sk) bytes or NULL;
+ * P and dS: bf16 (B, H, Sq, ldp), ldp = pad8(Sk), padding columns written as 0.  Replaces bmhrl_attn_delta + the PROB and
+ * DSCORE GEMM epilogues of bmhrl_gemm for these shapes.  _ok: 1 when the shape is served (dk == 256, Sk <= 256, key mask). */
+int bmhrl_attention_bwd_scores256_ok(int32_t Sq, int32_t Sk, int32_t dk, int64_t mask_sq);
+int bmhrl_attention_bwd_scores256(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                                  const void* dO, int64_t lddo, const float* row_max, const float* row_sum,
+                                  const uint8_t* mask, int64_t mask_sb, void* P, void* dS, int64_t ldp, int32_t B, int32_t H,
+                                  int32_t Sq, int32_t Sk, float scale, bmhrl_stream_t stream);
+
 /* delta[b,h,q] = scale * sum_d dO[b,q,h,d] * O[b,q,h,d]   (softmax backward row term) */
 int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale,
                      int32_t B, int32_t H, int32_t Sq, int32_t DK, bmhrl_stream_t stream);

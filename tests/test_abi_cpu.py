@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
                                     "bmhrl_memory_attention_ok"} == set(syms)
     assert lib.bmhrl_layernorm_bwd_workspace(4096, 1024) == 256 * 2 * 1024      # 4 rows per wave, 4 waves per block: 256 blocks
     assert lib.bmhrl_hip_arch() == b"gfx950"
-    assert lib.bmhrl_hip_abi_version() == 15
+    assert lib.bmhrl_hip_abi_version() == 16
     assert lib.bmhrl_attention_max_keys() == 10112        # pure host query: the fused kernels' key limit
     # pure host query too: the video projections' weight gradients store every element once, the caption-side ones split K
     assert lib.bmhrl_gemm_splits(1024, 1024, 4096, 1) == 1 and lib.bmhrl_gemm_splits(128, 300, 480, 1) > 1

@@ -38,7 +38,12 @@ def _agent(dev, g):
     assert mine == shapes                                   # the reference module's checkpoint layout, key for key
     sd = syn.fill_state_dict({k: s for k, s in shapes.items() if not k.startswith("critic.")}, seed=13)
     sd.update({"critic." + k: v for k, v in syn.synthetic_critic_state(20, seed=1).items()})
+    # worker_decoder.norm and manager_decoder.norm are ONE LayerNorm module in the reference (model/det_bmhrl_agent.py:52-53:
+    # `worker_norm = manager_norm = ...`) and here: a real checkpoint holds the same values under both keys
+    for leaf in ("weight", "bias"):
+        sd[f"worker_decoder.norm.{leaf}"] = sd[f"manager_decoder.norm.{leaf}"]
     agent.load_state_dict(sd)
+    assert agent.worker_decoder.norm is agent.manager_decoder.norm
     return agent.to(dev).eval(), cfg, sd
 
 
@@ -69,9 +74,8 @@ def test_detr_agent_against_the_reference_and_the_oracle(dev, golden):
         ref = O.detr_caption_forward(sd, cfg, torch.from_numpy(g["x_video"]), trg, masks_cpu)
         out = agent((x, None), trg.to(dev), {k: v.to(dev) for k, v in masks_cpu.items()})
         assert len(out) == 6 and out[3] is None and out[4] is None
-        # (bf16 operands through 3 convolutions + 18 post-norm layers at head width 16: the encoder memory / object states keep
-        # 3e-2 of their maximum, the log-probs behind the three decoder layers 6e-2)
-        assert rel(out[0], ref[0]) < 6e-2 and rel(out[1], ref[1]) < 6e-2 and rel(out[2], ref[2]) < 3e-2 and rel(out[5], ref[3]) < 3e-2
+        # (bf16 operands through 3 convolutions + 18 post-norm layers at head width 16)
+        assert rel(out[0], ref[0]) < 3e-2 and rel(out[1], ref[1]) < 3e-2 and rel(out[2], ref[2]) < 3e-2 and rel(out[5], ref[3]) < 3e-2
         assert torch.allclose(out[0].exp().sum(-1).cpu(), torch.ones(B, L), atol=1e-4)
         pred, _, _ = agent.inference((x, None), trg.to(dev), {k: v.to(dev) for k, v in masks_cpu.items()}, None, None)
         assert torch.equal(pred, out[0])
