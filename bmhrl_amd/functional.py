@@ -199,6 +199,15 @@ class ScratchState:
         self.need_raw = 0
         self.pool = {}
         self.sync = None                               # the four sync words of ops.head_loss (re-armed by the kernel itself)
+        # data-parallel steps: leaf gradients are produced IN their slices of the optimiser's flat bucket instead of the arena
+        # (train.FlatAdam.adopt_homes).  homes: (arena kind, element offset) of an allocation of the step -> its bucket view;
+        # home_buckets: the buckets, zeroed with the arena at the start of a step; log: allocations of the current step
+        # [(kind, offset, elements, data_ptr, storage)] while record is set (the storage is kept so that no address repeats; not the
+        # tensor: autograd only adopts a gradient nobody else holds) (the warm-up pass the homes are derived from)
+        self.homes = {}
+        self.home_buckets = []
+        self.record = False
+        self.log = []
 
 
 class StepScratch:
@@ -252,6 +261,16 @@ class StepScratch:
             else:
                 self.arena[:self.off_of_last_step()].zero_()
         st = self.state
+        for bucket in st.home_buckets:                  # (gradients accumulate into / skip parts of their bucket slices too)
+            if zero_stream is not None:
+                if self._zeroing is None:
+                    zero_stream.wait_stream(torch.cuda.current_stream())
+                    self._zeroing = zero_stream
+                with torch.cuda.stream(zero_stream):
+                    bucket.zero_()
+            else:
+                bucket.zero_()
+        st.log = []
         if st.need_raw and (st.raw is None or st.raw.device != device or st.raw.numel() < st.need_raw):
             st.raw = torch.empty(st.need_raw, device=device)
         if st.raw is not None and _ARENA_POISON:
@@ -299,24 +318,43 @@ class StepScratch:
         for d in shape:
             n *= d
         n4 = (n + 3) & ~3
+        st = self.state
         if not zero:
-            r = self.state.raw
+            r = st.raw
             if not self.armed or r is None or r.device != device or self.off_raw + n4 > r.numel():
+                t = torch.empty(*shape, device=device)
                 if self.armed:
+                    if st.record:     # (the offset this allocation gets once the arena has been sized: every request so far fits)
+                        st.log.append((1, self.off_raw + self.spill_raw, n, t.data_ptr(), t.untyped_storage()))
                     self.spill_raw += n4
-                return torch.empty(*shape, device=device)
-            t = r[self.off_raw:self.off_raw + n].view(*shape)
+                return t
+            off = self.off_raw
             self.off_raw += n4
+            home = st.homes.get((1, off + self.spill_raw))
+            if home is not None and home.numel() == n:
+                return home.view(*shape)
+            t = r[off:off + n].view(*shape)
+            if st.record:
+                st.log.append((1, off + self.spill_raw, n, t.data_ptr(), t.untyped_storage()))
             return t
         a = self.arena
         if self._zeroing is not None:
             self.join_zero()
         if not self.armed or a is None or a.device != device or self.off + n4 > a.numel():
+            t = torch.zeros(*shape, device=device)
             if self.armed:
+                if st.record:
+                    st.log.append((0, self.off + self.spill, n, t.data_ptr(), t.untyped_storage()))
                 self.spill += n4
-            return torch.zeros(*shape, device=device)
-        t = a[self.off:self.off + n].view(*shape)
+            return t
+        off = self.off
         self.off += n4
+        home = st.homes.get((0, off + self.spill))
+        if home is not None and home.numel() == n:
+            return home.view(*shape)
+        t = a[off:off + n].view(*shape)
+        if st.record:
+            st.log.append((0, off + self.spill, n, t.data_ptr(), t.untyped_storage()))
         return t
 
     def memo_bf16(self, t: torch.Tensor, rows: int, cols: int, copies: int = 1) -> torch.Tensor:

@@ -31,6 +31,7 @@ class FlatAdam:
 
     def __init__(self, params: List[torch.nn.Parameter], lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.params = [p for p in params]
+        self.params0 = list(self.params)          # construction order (in_param_order)
         dev = self.params[0].device
         self.sizes = [p.numel() for p in self.params]
         self.offsets = []
@@ -97,7 +98,8 @@ class FlatAdam:
         sig = tuple((kind, key, buf.data_ptr()) for kind, key, buf, _, _ in groups)
         gptrs = self.__dict__.get("_direct_ptrs")
         cached = self.__dict__.get("_seg_plan")
-        if gptrs is not None and self.__dict__.get("_grad_dirty", True) and not torch.cuda.is_current_stream_capturing():
+        if gptrs is not None and self.__dict__.get("_grad_dirty", True) and not torch.cuda.is_current_stream_capturing() \
+                and not self.__dict__.get("_homes", False):       # (homes: the bucket holds this step's gradients, zeroed at its start)
             # the direct path reads the bucket only for parameters without a gradient: they must find zeros there, also when
             # a cached plan is reused after a step that went through the gather path (which leaves gradients in the bucket)
             self.grad.zero_()
@@ -199,7 +201,7 @@ class FlatAdam:
         for p, gv in zip(self.params[lo:hi], self.grad_views[lo:hi]):
             if p.grad is None:
                 missing.append(gv)
-            else:
+            elif p.grad.data_ptr() != gv.data_ptr():          # (equal: produced in place, adopt_homes)
                 dst.append(gv)
                 src.append(p.grad)
         self._grad_dirty = True
@@ -223,6 +225,106 @@ class FlatAdam:
             plans[part] = (sig, torch.tensor(rows, dtype=torch.int64).to(self.flat.device), len(rows), blk)
         _, table, n_seg, n_blk = plans[part]
         ops.cast_segments(table, n_seg, n_blk)
+
+    def in_param_order(self, t: torch.Tensor) -> torch.Tensor:
+        """a flat tensor of this optimiser (flat / grad / exp_avg ...) as the concatenation of its parameters' slices in
+        CONSTRUCTION order: independent of the bucket layout (adopt_homes moves parameters inside their buckets)"""
+        where = {id(p): (o, n) for p, o, n in zip(self.params, self.offsets, self.sizes)}
+        return torch.cat([t[where[id(p)][0]:where[id(p)][0] + where[id(p)][1]] for p in self.params0])
+
+    def _relayout(self, order: List[int]):
+        """Re-home the parameters (and the Adam state) in the order `order`, a permutation of parameter indices that keeps
+        every parameter inside its bucket"""
+        old = {id(p): (o, n) for p, o, n in zip(self.params, self.offsets, self.sizes)}
+        params = [self.params[i] for i in order]
+        offsets, n = [], 0
+        for i in order:
+            offsets.append(n)
+            n += (self.sizes[i] + 3) & ~3
+        dev = self.flat.device
+        new = {name: torch.zeros(n, device=dev) for name in ("flat", "exp_avg", "exp_avg_sq")}
+        for name, buf in new.items():
+            src = getattr(self, name)
+            torch._foreach_copy_([buf[o:o + p.numel()] for p, o in zip(params, offsets)],
+                                 [src[old[id(p)][0]:old[id(p)][0] + old[id(p)][1]] for p in params])
+        self.params, self.offsets, self.sizes, self.n = params, offsets, [p.numel() for p in params], n
+        self.flat, self.exp_avg, self.exp_avg_sq = new["flat"], new["exp_avg"], new["exp_avg_sq"]
+        self.grad = torch.zeros(n, device=dev)
+        for p, o, sz in zip(self.params, self.offsets, self.sizes):
+            p.data = self.flat[o:o + sz].view(p.shape)
+        self.grad_views = [self.grad[o:o + sz].view(p.shape) for p, o, sz in zip(self.params, self.offsets, self.sizes)]
+        for k in ("_index", "_seg_plan", "_gather_plans", "_direct_ptrs", "_part_plans"):
+            self.__dict__.pop(k, None)
+        if self.__dict__.get("bucket_bounds") is not None:
+            self.split_off = self._elem_off(self.bucket_bounds[1])
+        SHADOWS.invalidate()
+
+    def adopt_homes(self, state: ScratchState) -> int:
+        """More than one rank: from now on the step's kernels write the leaf gradients straight into the flat bucket, which is
+        what the all-reduce wants side by side -- gather_grads() then copies only what could not be placed.
+        `state`: the trainer's ScratchState after a pass run with state.record set (p.grad still alive).  An allocation of that
+        pass that the gradients of some parameters tile exactly (one weight; or the stacked [q; k; v] x two-stacks block of a
+        paired layer, six parameters) becomes a contiguous run of the bucket: the parameters are moved next to each other
+        inside their bucket, in the allocation's order (_relayout), and StepScratch.f32 hands out that run of self.grad instead
+        of the arena slice.  A parameter with two consumers keeps working (autograd keeps the first producer's buffer and
+        adds into it).  Returns the number of gradient elements that now skip the copy."""
+        import bisect
+        log = sorted(state.log, key=lambda r: r[3])
+        starts = [r[3] for r in log]
+        members = {}                                     # index into log -> [(byte offset in the allocation, param index)]
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.numel() != p.numel():
+                continue
+            j = bisect.bisect_right(starts, g.data_ptr()) - 1
+            if j >= 0 and g.data_ptr() + 4 * g.numel() <= log[j][3] + 4 * log[j][2]:
+                members.setdefault(j, []).append((g.data_ptr() - log[j][3], i))
+        bucket_of = {}
+        bounds = self.__dict__.get("bucket_bounds") or [0, len(self.params)]
+        for b, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
+            for i in range(lo, hi):
+                bucket_of[i] = b
+        runs = []                                        # (log row, [param indices in allocation order])
+        for j, mem in members.items():
+            mem.sort()
+            off, ok = 0, True
+            for o, i in mem:
+                ok = ok and o == off
+                off += 4 * self.sizes[i]
+            ok = ok and off == 4 * log[j][2] and len({bucket_of[i] for _, i in mem}) == 1
+            ok = ok and (len(mem) == 1 or all(self.sizes[i] % 4 == 0 for _, i in mem))
+            if ok:
+                runs.append((log[j], [i for _, i in mem]))
+        runs.sort(key=lambda r: (r[0][0], r[0][1]))      # allocation order
+        in_run = {i: k for k, (_, idx) in enumerate(runs) for i in idx}
+        order, done = [], set()
+        for i in range(len(self.params)):                # bucket by bucket (the buckets are index ranges): runs first-come
+            if i in done:
+                continue
+            group = runs[in_run[i]][1] if i in in_run else [i]
+            order += group
+            done.update(group)
+        # (a run's members all sit in one bucket and `order` only moves a parameter to the position of the first member of
+        # its run: the multiset of parameters per bucket range is unchanged only if runs do not straddle -- checked above)
+        per_bucket = [sorted(order[lo:hi]) == list(range(lo, hi)) for lo, hi in zip(bounds, bounds[1:])]
+        if not all(per_bucket):
+            return 0
+        self._relayout(order)
+        pos_of_old = {old_i: k for k, old_i in enumerate(order)}     # (the members of a run are consecutive now)
+        placed = 0
+        for row, idx in runs:
+            o0, n, off = self.offsets[pos_of_old[idx[0]]], row[2], 0
+            ok = True
+            for i in idx:
+                ok = ok and self.offsets[pos_of_old[i]] == o0 + off
+                off += self.sizes[pos_of_old[i]]
+            if ok and off == n:
+                state.homes[(row[0], row[1])] = self.grad[o0:o0 + n]
+                placed += n
+        if placed:
+            state.home_buckets.append(self.grad)
+            self._homes = True
+        return placed
 
     def all_reduce(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -547,16 +649,28 @@ class CaptionTrainer:
             s = CaptionTrainer._warm_streams[self.device] = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            if self.scratch.arena is None:
+            homes = self._grad_homes_wanted()
+            if self.scratch.arena is None or homes:
                 # size this trainer's scratch arena first: a pass without the optimizer (weights untouched).  The warm-up
                 # steps below then already work on the arena slices the captured step will use -- the Adam pass reads the
-                # gradients where autograd leaves them, and its table holds those addresses
+                # gradients where autograd leaves them, and its table holds those addresses.
+                # Data parallel: the same pass records which allocation every leaf gradient comes from; from the next pass on
+                # they are produced in the flat bucket (FlatAdam.adopt_homes moves the parameters of a stacked allocation
+                # next to each other inside their bucket first -- before any captured address exists)
                 self._sync_token_weight(self.static["captions"])
+                self.scratch.record = homes
                 self._graph_body_a()
                 if self._split():
                     for j in range(1, self.n_enc + 1):
                         self._graph_body_phase(j)
+                if homes:
+                    self.scratch.record = False
+                    self.grad_elems_in_place = self.opt.adopt_homes(self.scratch)
+                    if self.value_net is not None:
+                        self.vopt.adopt_homes(self.scratch)
                 self.opt.zero_grad()
+                if self.value_net is not None:
+                    self.vopt.zero_grad()
                 SEEDS.dev.sub_(1)             # (the pass does not count as a step: dropout masks / samples continue as if it had not run)
                 self.opt.step_dev.sub_(1)     # (nor do the optimisers' device counters, which the step's first launch advanced)
                 if self.value_net is not None:
@@ -619,6 +733,17 @@ class CaptionTrainer:
     @staticmethod
     def _world_scale():
         return 1.0 / dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1.0
+
+    def _grad_homes_wanted(self) -> bool:
+        """leaf gradients written straight into the flat bucket (FlatAdam.adopt_homes): with more than one rank, where the
+        bucket is what the all-reduce reads; BMHRL_GRAD_HOMES=1 / 0 forces it on (one-rank rehearsal) / off (A/B).  Adopted
+        once per trainer."""
+        if self.scratch.homes or self.device.type != "cuda":
+            return False
+        env = os.environ.get("BMHRL_GRAD_HOMES")
+        if env in ("0", "1"):
+            return env == "1"
+        return self._world_scale() != 1.0
 
     def _phased_one_rank(self) -> bool:
         return self.phased_adam and self.split_backward is None and self._world_scale() == 1.0 and self.device.type == "cuda" \

@@ -58,7 +58,8 @@ def _worker(rank, world, port, out):
     b = _batch([40 + rank], dev)
     loss = _run(tr, b)
     n_tok = int((b["captions"][:, 1:] != 1).sum())
-    out[rank] = (tr.opt.flat.cpu(), (tr.opt.grad / world).cpu(), loss, n_tok, float(tr.loss_weight))
+    out[rank] = (tr.opt.in_param_order(tr.opt.flat).cpu(), (tr.opt.in_param_order(tr.opt.grad) / world).cpu(), loss, n_tok,
+                 float(tr.loss_weight), getattr(tr, "grad_elems_in_place", 0) / tr.opt.n)
     dist.destroy_process_group()
 
 
@@ -69,8 +70,9 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    flat0, grad0, loss0, n0, w0 = out[0]
-    flat1, grad1, loss1, n1, w1 = out[1]
+    flat0, grad0, loss0, n0, w0, in_place = out[0]
+    flat1, grad1, loss1, n1, w1, _ = out[1]
+    assert in_place > 0.95           # the leaf gradients are produced in the flat bucket (FlatAdam.adopt_homes): no 221 MB gather
     assert torch.equal(flat0, flat1) and torch.equal(grad0, grad1)          # replicas: bit-identical
     assert n0 != n1                                                          # the ranks really see different token counts
     assert abs(w0 - 2 * n0 / (n0 + n1)) < 1e-6 and abs(w1 - 2 * n1 / (n0 + n1)) < 1e-6
@@ -82,12 +84,12 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     tr.opt.direct_grads = False          # this check reads the gathered bucket (one process normally leaves the gradients in place)
     b = _batch([40, 41], dev)
     loss = _run(tr, b)
-    ref_grad = tr.opt.grad.cpu()
+    ref_grad = tr.opt.in_param_order(tr.opt.grad).cpu()
     # loss of the whole batch = token-weighted mean of the ranks' losses (their reported loss carries the weight already)
     assert abs(loss - 0.5 * (loss0 + loss1)) <= 2e-3 * abs(loss)
     err = float((grad0 - ref_grad).norm() / ref_grad.norm())
     assert err <= 3e-2, err                                                   # bf16 operands, different tile paths for B=2 / B=4
-    upd = float((flat0 - tr.opt.flat.cpu()).abs().max())
+    upd = float((flat0 - tr.opt.in_param_order(tr.opt.flat).cpu()).abs().max())
     assert upd <= 2.5e-4, upd                                                 # two Adam steps of lr 1e-4: at most 2e-4 apart
 
 
@@ -101,7 +103,8 @@ def _rl_worker(rank, world, port, out):
     assert tr._split()                               # the RL phases take the phased backward too
     b = _batch([40 + rank], dev)
     loss = _run(tr, b)
-    out[rank] = (tr.opt.flat.cpu(), (tr.opt.grad / world).cpu(), (tr.vopt.grad / world).cpu(), tr.vopt.flat.cpu(), loss,
+    out[rank] = (tr.opt.in_param_order(tr.opt.flat).cpu(), (tr.opt.in_param_order(tr.opt.grad) / world).cpu(),
+                 (tr.vopt.in_param_order(tr.vopt.grad) / world).cpu(), tr.vopt.in_param_order(tr.vopt.flat).cpu(), loss,
                  float(tr.last_value_loss))
     dist.destroy_process_group()
 
@@ -127,9 +130,10 @@ def test_two_ranks_worker_rl_phase_equal_one_process():
     tr.opt.direct_grads = tr.vopt.direct_grads = False
     b = _batch([40, 41], dev)
     _run(tr, b)
-    ref_grad, ref_vgrad = tr.opt.grad.cpu(), tr.vopt.grad.cpu()
+    ref_grad, ref_vgrad = tr.opt.in_param_order(tr.opt.grad).cpu(), tr.vopt.in_param_order(tr.vopt.grad).cpu()
     assert abs(float(tr.last_value_loss) - 0.5 * (vl0 + vl1)) <= 2e-2 * abs(float(tr.last_value_loss))
     err = float((grad0 - ref_grad).norm() / ref_grad.norm())
     verr = float((vgrad0 - ref_vgrad).norm() / ref_vgrad.norm())
     assert err <= 3e-2 and verr <= 5e-2, (err, verr)
-    assert float((flat0 - tr.opt.flat.cpu()).abs().max()) <= 2.5e-4 and float((vflat0 - tr.vopt.flat.cpu()).abs().max()) <= 2.5e-4
+    assert float((flat0 - tr.opt.in_param_order(tr.opt.flat).cpu()).abs().max()) <= 2.5e-4
+    assert float((vflat0 - tr.vopt.in_param_order(tr.vopt.flat).cpu()).abs().max()) <= 2.5e-4

@@ -212,3 +212,51 @@ def test_detr_agent_checkpoint_layout_matches_the_reference():
     agent.teach_worker()
     assert not agent.manager.exploration and all(p.requires_grad for p in agent.linear.parameters())
     assert not any(p.requires_grad for p in agent.manager_decoder.parameters())
+
+
+def test_flat_adam_adopts_gradient_homes_and_keeps_values():
+    """FlatAdam.adopt_homes (data-parallel steps produce the leaf gradients in the flat bucket): parameters whose gradients
+    tile one recorded allocation are moved next to each other inside their bucket, values and Adam state move with them, the
+    allocation maps to one contiguous run of the bucket, and whatever does not tile an allocation stays on the copy path."""
+    import torch
+    from bmhrl_amd.functional import ScratchState
+    from bmhrl_amd.train import FlatAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(8, 4), (4,), (8, 4), (4,), (12, 4), (3,), (16,)]          # w_a, b_a, w_b, b_b, w_c, odd, lone
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    opt = FlatAdam(params, lr=1e-3)
+    opt.set_buckets([4, 3])
+    opt.exp_avg.copy_(torch.randn(opt.n, generator=g))
+    before = opt.in_param_order(opt.flat).clone(), opt.in_param_order(opt.exp_avg).clone()
+    st = ScratchState()
+    stacked_w = torch.randn(16, 4, generator=g)          # [w_a; w_b]: one allocation, two parameters of bucket 0
+    stacked_b = torch.randn(8, generator=g)              # [b_a; b_b]
+    own = torch.randn(12, 4, generator=g)                # w_c alone
+    mixed = torch.randn(3 + 16, generator=g)             # odd + lone: a member of 3 elements -> cannot be glued
+    other = torch.randn(5, generator=g)                  # an allocation no parameter uses
+    st.log = [(0, 0, 64, stacked_w.data_ptr(), stacked_w), (0, 64, 8, stacked_b.data_ptr(), stacked_b),
+              (1, 0, 48, own.data_ptr(), own), (0, 72, 19, mixed.data_ptr(), mixed), (0, 92, 5, other.data_ptr(), other)]
+    grads = [stacked_w[:8], stacked_b[:4], stacked_w[8:], stacked_b[4:], own, mixed[:3], mixed[3:]]
+    for p, gr in zip(params, grads):
+        p.grad = gr
+    placed = opt.adopt_homes(st)
+    assert placed == 64 + 8 + 48
+    assert torch.equal(opt.in_param_order(opt.flat), before[0]) and torch.equal(opt.in_param_order(opt.exp_avg), before[1])
+    for p, v in zip(params, before[0].split([p.numel() for p in params])):
+        assert torch.equal(p.data.reshape(-1), v) and p.data.data_ptr() >= opt.flat.data_ptr()
+    assert set(st.homes) == {(0, 0), (0, 64), (1, 0)} and st.home_buckets[0] is opt.grad
+    # the run of [w_a; w_b] is one contiguous piece of the bucket, w_a first
+    ia, ib = [k for k, p in enumerate(opt.params) if p is params[0]][0], [k for k, p in enumerate(opt.params) if p is params[2]][0]
+    assert ib == ia + 1 and opt.offsets[ib] == opt.offsets[ia] + 32
+    assert st.homes[(0, 0)].data_ptr() == opt.grad_views[ia].data_ptr() and st.homes[(0, 0)].numel() == 64
+    # buckets keep their members
+    assert {id(p) for p in opt.params[:4]} == {id(p) for p in params[:4]}
+    # a step that produces the gradients at home copies only the rest
+    for k, p in enumerate(opt.params):
+        p.grad = opt.grad_views[k] if any(p is q for q in params[:5]) else torch.ones_like(p)
+    opt.grad.zero_()
+    opt.grad_views[ia].fill_(2.0)
+    opt.gather_grads()
+    assert float(opt.grad_views[ia].min()) == 2.0                     # untouched (its own memory)
+    odd = [k for k, p in enumerate(opt.params) if p is params[5]][0]
+    assert float(opt.grad_views[odd].min()) == 1.0                    # copied

@@ -22,7 +22,7 @@ def test_split_backward_equals_single_phase():
         t.agent.train()
         t.split_backward = split
         init = t.opt.flat.clone()
-        t.capture(fs, cap, warmup=2)
+        t.capture(fs, cap, warmup=1)
         losses = [float(t.replay()) for _ in range(3)]
         assert hasattr(t, "graph_a2") == split
         if split:
@@ -63,7 +63,7 @@ t.agent.train()
 t.split_backward = sys.argv[2] == "split"
 t.capture(fs, cap, warmup=1)
 losses = [float(t.replay()) for _ in range(3)]
-torch.save({"losses": losses, "flat": t.opt.flat.cpu()}, sys.argv[1])
+torch.save({"losses": losses, "flat": t.opt.in_param_order(t.opt.flat).cpu(), "in_place": getattr(t, "grad_elems_in_place", 0), "n": t.opt.n}, sys.argv[1])
 """
 
 
@@ -87,3 +87,32 @@ def test_deterministic_mode_runs_agree_bit_for_bit(tmp_path):
     assert outs[0]["losses"] == outs[1]["losses"] and torch.equal(outs[0]["flat"], outs[1]["flat"])
     assert outs[0]["losses"] == outs[2]["losses"] and torch.equal(outs[0]["flat"], outs[2]["flat"])
     assert all(x == x for x in outs[0]["losses"]) and outs[0]["losses"][2] < outs[0]["losses"][0]
+
+
+def test_gradients_produced_in_the_flat_bucket_change_nothing(tmp_path):
+    """Data-parallel runs write the leaf gradients straight into their slices of the optimiser's flat bucket
+    (FlatAdam.adopt_homes, on by itself with more than one rank); rehearsed on one rank with BMHRL_GRAD_HOMES=1 and the gather
+    path forced (BMHRL_DIRECT_GRADS=0, what a multi-rank step runs): in deterministic mode losses and weights are IDENTICAL to
+    the run that gathers every gradient, for the single-phase and the phased backward, and nearly every element skips the copy."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, BMHRL_DETERMINISTIC="1", BMHRL_DIRECT_GRADS="0",
+                PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    outs = {}
+    for homes in ("0", "1"):
+        for mode in ("single", "split"):
+            f = tmp_path / f"run_{homes}_{mode}.pt"
+            r = subprocess.run([sys.executable, "-c", _DET_SCRIPT, str(f), mode], env=dict(base, BMHRL_GRAD_HOMES=homes),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[homes, mode] = torch.load(f)
+    ref = outs["0", "single"]
+    for key, o in outs.items():
+        assert o["losses"] == ref["losses"] and torch.equal(o["flat"], ref["flat"]), key
+    assert outs["0", "single"]["in_place"] == 0
+    for mode in ("single", "split"):
+        assert outs["1", mode]["in_place"] > 0.95 * outs["1", mode]["n"], (mode, outs["1", mode]["in_place"], outs["1", mode]["n"])
