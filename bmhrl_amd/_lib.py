@@ -160,6 +160,7 @@ def load() -> C.CDLL:
     lib.bmhrl_gemm_splits.restype = C.c_int
     lib.bmhrl_hip_arch.restype = C.c_char_p
     lib.bmhrl_hip_abi_version.restype = C.c_int
+    lib.bmhrl_deterministic_enabled.restype = C.c_int
     _lib = lib
     return lib
 

@@ -1591,4 +1591,6 @@ extern "C" const char* bmhrl_hip_arch(void) { return "gfx950"; }
 //     bmhrl_sample_tokens row_offset, bmhrl_attention_max_keys, bmhrl_token_loss_reduce, bmhrl_fusion_tail_fwd / _bwd
 // 11: bmhrl_batch_head, bmhrl_smooth_kl_bwd loss_scale2, bmhrl_layernorm_fwd_groups / _bwd_groups, bmhrl_colsum_bf16_groups,
 //     bmhrl_cast_bf16_copies
-extern "C" int bmhrl_hip_abi_version(void) { return 16; }
+extern "C" int bmhrl_hip_abi_version(void) { return 17; }
+// the ONE reading of BMHRL_DETERMINISTIC (common.h): the host side asks here instead of parsing the variable again
+extern "C" int bmhrl_deterministic_enabled(void) { return bmhrl_deterministic() ? 1 : 0; }

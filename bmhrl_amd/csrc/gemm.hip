@@ -1388,7 +1388,8 @@ extern "C" int bmhrl_gemm_group(const bmhrl_gemm_desc* d, int32_t n, bmhrl_strea
     if (const int rc = prepare(d + i, *ps[i], tp, batch)) return rc;
     GemmArgs& p = *ps[i];
     same = same && !tp.big && !tp.mid && d[i].a_trans == d[0].a_trans && d[i].b_trans == d[0].b_trans &&
-           !uses_glds(p, d[i].a_trans, d[i].b_trans) && p.split_ws == nullptr;
+           !uses_glds(p, d[i].a_trans, d[i].b_trans) && p.split_ws == nullptr &&
+           !(bmhrl_deterministic() && p.colsum != nullptr);      // (ordered column sums are a pass of bmhrl_gemm)
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_mn = p.tiles_m * ((p.N + 63) / 64);
     p.splits = tp.splits;

@@ -235,6 +235,7 @@ class StepScratch:
         self.memo = {}
         self.memo_hits = 0           # memo_bf16 calls served without a cast (a producer's offer or an earlier call)
         self._zeroing = None
+        self._zero_origin = None
 
     # (the buffers live in the bound state)
     arena = property(lambda self: self.state.arena, lambda self, v: setattr(self.state, "arena", v))
@@ -250,6 +251,7 @@ class StepScratch:
             return
         self.state = state if state is not None else self.default_state
         self._zeroing = None
+        self._zero_origin = torch.cuda.current_stream() if zero_stream is not None else None
         if self.arena is None or self.arena.device != device or self.arena.numel() < self.need:
             self.arena = torch.zeros(self.need, device=device) if self.need else None
         elif self.off_of_last_step():
@@ -300,9 +302,16 @@ class StepScratch:
         return min(self.state.need, self.arena.numel()) if self.arena is not None else 0
 
     def join_zero(self):
-        """the current stream waits for the arena's fill (begin_step(zero_stream=...)); call on the stream the step runs on"""
+        """the arena's fill (begin_step(zero_stream=...)) is joined into the stream it was forked FROM -- the step's own stream,
+        which every side stream of the backward is forked from later -- and, when somebody asks for arena memory from another
+        stream first, into that stream as well (a join into the asking stream alone would leave the step's stream unordered
+        against the fill)"""
         if self._zeroing is not None:
-            torch.cuda.current_stream().wait_stream(self._zeroing)
+            cur = torch.cuda.current_stream()
+            origin = self._zero_origin if self._zero_origin is not None else cur
+            origin.wait_stream(self._zeroing)
+            if cur != origin:
+                cur.wait_stream(self._zeroing)
             self._zeroing = None
 
     def end_step(self):
@@ -505,7 +514,7 @@ def _attn_core_bwd(dOb, Ob, stats, Qb, q_off, ldq, Kb, k_off, ldk, Vb, v_off, ld
     if stats[0] == "mat" and _use_small(dk, Sq, Sk, ldq, ldk, ldv, lddq, lddk, lddv, q_off, k_off, v_off, dq_off, dk_off, dv_off):
         t = lambda d: (None, 0) if d is None else d
         (bq, oq), (bk, ok), (bv, ov) = t(db_q), t(db_k), t(db_v)
-        if ops.DETERMINISTIC and (bq is not None or bk is not None or bv is not None):
+        if ops.deterministic() and (bq is not None or bk is not None or bv is not None):
             # the kernel's bias sums are one atomic per (sample, head) block and column: ordered column sums afterwards instead
             ops.small_attention_bwd(dOb, H * dk, stats[1], pad8(Sk), Qb, Kb, Vb, dQb, dKb, dVb, mask, msb, msq, B, H, Sq, Sk, dk,
                                     1.0 / math.sqrt(dk), ldq, ldk, ldv, lddq, lddk, lddv, q_off=q_off, k_off=k_off, v_off=v_off,

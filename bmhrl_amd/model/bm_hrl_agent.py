@@ -172,7 +172,14 @@ class BMFusionLayer(nn.Module):
     absorb_memory_projections = True
     # normCA, normCV and the gate as one launch (functional.FusionTailFn); its parameter gradients are per-block atomics, so
     # BMHRL_DETERMINISTIC takes the separate LayerNorm / gate kernels (ordered sums)
-    fused_tail = os.environ.get("BMHRL_FUSED_TAIL", "1") == "1" and os.environ.get("BMHRL_DETERMINISTIC", "0") in ("", "0")
+    _fused_tail_env = os.environ.get("BMHRL_FUSED_TAIL", "1") == "1"
+
+    class _FusedTail:            # (read lazily: the deterministic switch is the library's reading of the variable, ops.deterministic)
+        def __get__(self, obj, owner):
+            from .. import ops
+            return owner._fused_tail_env and not ops.deterministic()
+
+    fused_tail = _FusedTail()
 
     def _tail_params(self):
         return (self.normCA.weight, self.normCA.bias, self.normCV.weight, self.normCV.bias, self.a_v_constant)

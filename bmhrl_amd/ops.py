@@ -265,13 +265,21 @@ def layernorm_fwd_groups(x, gamma, beta, y_bf16, ldy, y_f32, mean, rstd, rows_pe
                "bmhrl_layernorm_fwd_groups")
 
 
-DETERMINISTIC = os.environ.get("BMHRL_DETERMINISTIC", "0") not in ("", "0")   # (the library reads the same variable)
+def deterministic() -> bool:
+    """BMHRL_DETERMINISTIC as the LIBRARY reads it (bmhrl_deterministic_enabled: one parse for both sides)"""
+    global _DETERMINISTIC
+    if _DETERMINISTIC is None:
+        _DETERMINISTIC = bool(_lib.load().bmhrl_deterministic_enabled())
+    return _DETERMINISTIC
+
+
+_DETERMINISTIC = None
 
 
 def layernorm_bwd_groups(dy, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, rows_per_group, D, groups):
     """backward of layernorm_fwd_groups; dgamma / dbeta (groups, D) are ADDED to (zero them first)"""
     _need_cuda(x)
-    if DETERMINISTIC:           # ordered parameter gradients: the two-stage form with a workspace per call, group by group
+    if deterministic():         # ordered parameter gradients: the two-stage form with a workspace per call, group by group
         R = rows_per_group
         for g in range(groups):
             sl = lambda t, n: None if t is None else t.reshape(-1)[g * n:(g + 1) * n]

@@ -495,14 +495,22 @@ class CaptionTrainer:
         # every side stream of the backward three times and cost more than the 0.2 ms of Adam they hide; off by default.
         self.phased_adam = os.environ.get("BMHRL_PHASED_ADAM", "0") == "1"
         self._layer_out = {}
+        self._keep_cuts = False
         for i, layer in enumerate(enc_layers):   # (V-stream, A-stream) after layer i: the cut between two backward phases
-            layer.register_forward_hook(lambda mod, inp, out, i=i: self._layer_out.__setitem__(i, out))
+            # kept only while a phased step is being built (and dropped with its last phase): a layer output held past the end
+            # of a step keeps that step's whole autograd graph alive -- memory, and objects of an eager pass that then die in
+            # the middle of a later capture (DESIGN.md section 10 "r04")
+            layer.register_forward_hook(lambda mod, inp, out, i=i: self._layer_out.__setitem__(i, out) if self._keep_cuts else None)
         self.modality = "audio_video"
         self.scratch = ScratchState()       # arena + operand pools of this trainer's steps: a captured step keeps their addresses
         self.graph = None
         self.static = None
         self.loss_weight = torch.ones((), device=self.device)   # token_weight() of the current batch (1 on one rank)
-        SEEDS.dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # the device seed word of THIS trainer's steps (bumped by the step's first launch, read by every dropout / sampling
+        # kernel): a captured step holds its address, so it lives with the trainer -- a process-wide word re-created by the next
+        # trainer's constructor left the first trainer's graph bumping freed memory
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        SEEDS.dev = self.seed_dev
 
     # ------------------------------------------------------------------ one step, eager
     def _head(self, fs, captions):
@@ -588,8 +596,33 @@ class CaptionTrainer:
             self.loss_weight.copy_(token_weight((captions[:, 1:] != self.pad_idx).sum()))
 
     def step(self, fs, captions, rl=None):
-        """zero_grad -> forward -> loss -> backward -> (all-reduce) -> Adam.  Returns the loss (device scalar)."""
+        """zero_grad -> forward -> loss -> backward -> (all-reduce) -> Adam.  Returns the loss (device scalar).
+        Called on the device's default stream, the step runs on this process's warm-up stream instead (forked from and joined
+        into the default stream): an autograd graph built on the legacy default stream that is still referenced when a step
+        is captured later makes hipStreamEndCapture of this runtime fault (tests/probes/step_then_capture.py, DESIGN.md
+        section 10 "r04"); on any other stream it does not."""
+        if captions.is_cuda and torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device):
+            cur, s = torch.cuda.current_stream(self.device), self._warm_stream()
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                loss = self._step(fs, captions, rl)
+            cur.wait_stream(s)
+            loss.record_stream(cur)
+            return loss
+        return self._step(fs, captions, rl)
+
+    def _warm_stream(self):
+        """one warm-up / eager-step stream per device and process (torch's pool of 32 streams wraps)"""
+        s = CaptionTrainer._warm_streams.get(self.device)
+        if s is None:
+            s = CaptionTrainer._warm_streams[self.device] = torch.cuda.Stream(device=self.device)
+        return s
+
+    def _step(self, fs, captions, rl=None):
         self._sync_token_weight(captions)
+        SEEDS.dev = self.seed_dev
+        self._keep_cuts = False
+        self._layer_out.clear()
         self.opt.zero_grad()
         if self.value_net is not None:
             self.vopt.zero_grad()
@@ -597,7 +630,7 @@ class CaptionTrainer:
         trg_in, trg_y, masks = self._head(fs, captions)
         SHADOWS.refresh()
         loss, _ = self._forward_loss(fs, trg_in, trg_y, rl, masks)
-        loss.backward(gradient=self._unit_grad(loss))
+        self._backward(loss)
         self.opt.gather_grads()
         if self.value_net is not None:
             self.vopt.gather_grads()
@@ -609,6 +642,19 @@ class CaptionTrainer:
             self.vopt.all_reduce()
             self.vopt.step(scale, dev_step_advanced=adv)
         return loss.detach()
+
+    def _backward(self, loss):
+        """d loss / d every parameter of the trainer's optimisers, left in p.grad.  torch.autograd.grad rather than
+        loss.backward(): backward() delivers through the parameters' AccumulateGrad nodes, and such a node keeps the stream it
+        was first used on -- a parameter touched by an eager step on the default stream pulls that stream into every later
+        capture (autograd syncs the producing side stream with it: a nested fork / join, the shape hipStreamEndCapture of this
+        runtime does not survive).  grad() returns the gradients on the streams that produced them."""
+        leaves = [p for p in self.opt.params if p.requires_grad]
+        if self.value_net is not None:
+            leaves += [p for p in self.vopt.params if p.requires_grad]
+        outs = torch.autograd.grad(loss, leaves, grad_outputs=self._unit_grad(loss), allow_unused=True)
+        for p, g in zip(leaves, outs):
+            p.grad = g
 
     def _unit_grad(self, loss):
         """d loss / d loss as a constant kept for the trainer's lifetime (autograd otherwise fills a fresh one every step)"""
@@ -644,9 +690,7 @@ class CaptionTrainer:
         self.static["captions"] = captions.clone()
         self.static_loss = torch.zeros((), device=self.device)
         self.opt.phased_direct = self._phased_one_rank()
-        s = CaptionTrainer._warm_streams.get(self.device)      # one warm-up stream per device and process (the pool of 32 wraps)
-        if s is None:
-            s = CaptionTrainer._warm_streams[self.device] = torch.cuda.Stream(device=self.device)
+        s = self._warm_stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             homes = self._grad_homes_wanted()
@@ -671,7 +715,7 @@ class CaptionTrainer:
                 self.opt.zero_grad()
                 if self.value_net is not None:
                     self.vopt.zero_grad()
-                SEEDS.dev.sub_(1)             # (the pass does not count as a step: dropout masks / samples continue as if it had not run)
+                self.seed_dev.sub_(1)         # (the pass does not count as a step: dropout masks / samples continue as if it had not run)
                 self.opt.step_dev.sub_(1)     # (nor do the optimisers' device counters, which the step's first launch advanced)
                 if self.value_net is not None:
                     self.vopt.step_dev.sub_(1)
@@ -762,10 +806,13 @@ class CaptionTrainer:
     def _graph_body_a(self):
         st = self.static
         cap = st["captions"]
+        SEEDS.dev = self.seed_dev
         self.opt.zero_grad()
         if self.value_net is not None:
             self.vopt.zero_grad()
         SCRATCH.begin_step(self.device, self.scratch, zero_stream=self._zero_stream())
+        self._keep_cuts = self._split()
+        self._layer_out.clear()
         trg_in, trg_y, masks = self._head(st, cap)
         if not self.opt.fused_shadows:
             SHADOWS.invalidate()
@@ -791,7 +838,7 @@ class CaptionTrainer:
             if self.value_net is not None:
                 self.vopt.gather_grads()
         else:
-            loss.backward(gradient=self._unit_grad(loss))
+            self._backward(loss)
             self.opt.gather_grads()
             if self.value_net is not None:
                 self.vopt.gather_grads()
@@ -818,6 +865,7 @@ class CaptionTrainer:
         self.opt.gather_grads(j)
         if idx == 0:
             self._layer_out.clear()
+            self._keep_cuts = False
             SCRATCH.end_step()
 
     def _graph_body_b(self, scale):

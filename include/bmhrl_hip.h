@@ -508,6 +508,9 @@ int bmhrl_groupnorm_bwd(const float* dy, const float* x, const float* gamma, con
                         float* dgamma, float* dbeta, int32_t B, int32_t T, int32_t C, int32_t G, bmhrl_stream_t stream);
 
 int bmhrl_hip_abi_version(void);
+/* 1 when BMHRL_DETERMINISTIC selects the ordered sums (read once, by the library; atoi(value) != 0).  The host side asks
+ * here instead of parsing the variable itself, so both sides always agree. */
+int bmhrl_deterministic_enabled(void);
 
 #ifdef __cplusplus
 }

@@ -116,3 +116,53 @@ def test_gradients_produced_in_the_flat_bucket_change_nothing(tmp_path):
     assert outs["0", "single"]["in_place"] == 0
     for mode in ("single", "split"):
         assert outs["1", mode]["in_place"] > 0.95 * outs["1", mode]["n"], (mode, outs["1", mode]["in_place"], outs["1", mode]["n"])
+
+
+_ABA_SCRIPT = r"""
+import sys, torch
+from bmhrl_amd import synthetic as syn
+from bmhrl_amd.train import CaptionTrainer
+dev = torch.device("cuda:0")
+def batch(B, Tv, Ta, L, seed):
+    b = syn.synthetic_batch(B, Tv, Ta, L, 300, seed=seed)
+    return {k: b[k].to(dev) for k in ("rgb", "flow", "audio")}, b["captions"].to(dev)
+fa, ca = batch(2, 64, 100, 10, 2)
+A = CaptionTrainer(syn.default_cfg(dout_p=0.1), 300, dev, exploration=False, lr=1e-3)
+A.agent.train()
+A.capture(fa, ca, warmup=1)
+losses = [float(A.replay()) for _ in range(2)]
+if sys.argv[2] == "with_b":
+    # a second, LARGER trainer: its own scratch arena / operand pools / graph; eager steps and a capture of its own
+    fb, cb = batch(4, 128, 200, 14, 3)
+    Bt = CaptionTrainer(syn.default_cfg(dout_p=0.1), 300, dev, exploration=False, lr=1e-3, seed=5)
+    Bt.agent.train()
+    Bt.step(fb, cb)
+    Bt.capture(fb, cb, warmup=1)
+    lb = [float(Bt.replay()) for _ in range(2)]
+    assert all(x == x for x in lb)
+losses += [float(A.replay()) for _ in range(2)]
+torch.cuda.synchronize()
+torch.save({"losses": losses, "flat": A.opt.in_param_order(A.opt.flat).cpu()}, sys.argv[1])
+"""
+
+
+def test_a_captured_trainer_survives_a_larger_second_trainer(tmp_path):
+    """Capture trainer A, replay; build, step and capture a LARGER trainer B (its own ScratchState: arena, operand pools,
+    sync words); replay A again: A's graph must still read and write memory that is its own.  Deterministic mode, so the
+    check is equality with a run in which B never existed."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMHRL_DETERMINISTIC="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    outs = {}
+    for mode in ("alone", "with_b"):
+        f = tmp_path / f"aba_{mode}.pt"
+        r = subprocess.run([sys.executable, "-c", _ABA_SCRIPT, str(f), mode], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(f)
+    assert all(x == x for x in outs["alone"]["losses"])
+    assert outs["alone"]["losses"] == outs["with_b"]["losses"]
+    assert torch.equal(outs["alone"]["flat"], outs["with_b"]["flat"])
