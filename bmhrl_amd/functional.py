@@ -204,6 +204,7 @@ class ScratchState:
         # home_buckets: the buckets, zeroed with the arena at the start of a step; log: allocations of the current step
         # [(kind, offset, elements, data_ptr, storage)] while record is set (the storage is kept so that no address repeats; not the
         # tensor: autograd only adopts a gradient nobody else holds) (the warm-up pass the homes are derived from)
+        self.last_spill = -1                           # elements the last step could not take from the arenas (-1: no step yet)
         self.homes = {}
         self.home_buckets = []
         self.record = False
@@ -318,6 +319,7 @@ class StepScratch:
         self.join_zero()
         self.need = max(self.need, self.off + self.spill)
         self.state.need_raw = max(self.state.need_raw, self.off_raw + self.spill_raw)
+        self.state.last_spill = self.spill + self.spill_raw      # 0: every request of this step came from the arenas
         self.armed = False
 
     def f32(self, *shape, device, zero: bool = True) -> torch.Tensor:

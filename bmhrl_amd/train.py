@@ -135,7 +135,7 @@ class FlatAdam:
         # one table per bucket as well (first-block column rebased): the update of a bucket can be launched as soon as its
         # gradients are complete (CaptionTrainer, phased Adam), while backward goes on below it
         parts = []
-        bounds = self.__dict__.get("bucket_bounds")
+        bounds = self.__dict__.get("plan_bounds") or self.__dict__.get("bucket_bounds")   # (plan_bounds: a finer partition, see CaptionTrainer)
         if bounds is not None:
             for lo, hi in zip(bounds, bounds[1:]):
                 sub = [r[:5] + [r[5] - rows[lo][5]] + r[6:] for r in rows[lo:hi]]
@@ -253,7 +253,7 @@ class FlatAdam:
         for p, o, sz in zip(self.params, self.offsets, self.sizes):
             p.data = self.flat[o:o + sz].view(p.shape)
         self.grad_views = [self.grad[o:o + sz].view(p.shape) for p, o, sz in zip(self.params, self.offsets, self.sizes)]
-        for k in ("_index", "_seg_plan", "_gather_plans", "_direct_ptrs", "_part_plans"):
+        for k in ("_index", "_seg_plan", "_gather_plans", "_direct_ptrs", "_part_plans", "plan_bounds"):
             self.__dict__.pop(k, None)
         if self.__dict__.get("bucket_bounds") is not None:
             self.split_off = self._elem_off(self.bucket_bounds[1])
@@ -342,11 +342,13 @@ class FlatAdam:
                 return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
         return None
 
-    def step_part(self, part: int, grad_scale: float = 1.0, dev_step_advanced: bool = False):
+    def step_part(self, part: int, grad_scale: float = 1.0, dev_step_advanced: bool = False, first: Optional[bool] = None,
+                  last: Optional[bool] = None):
         """the update of bucket `part` alone (its gradients are complete; later buckets are still in backward).  Needs the
-        plan of a previous full step(); the step counters advance with bucket 0."""
+        plan of a previous full step(); the step counters advance with the first part of a step (default: part 0), shadows
+        nobody maintains go stale with the last (default: the highest part)."""
         b1, b2 = self.betas
-        if part == 0:
+        if (part == 0) if first is None else first:
             self.step_count += 1
             self.generation += 1
             if not dev_step_advanced:
@@ -355,7 +357,7 @@ class FlatAdam:
         if n_seg:
             ops.adam_segments(table, n_seg, n_blk, self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, b1, b2, self.eps,
                               self.weight_decay, self.step_count, grad_scale, step_dev=self.step_dev)
-        if part == len(self._part_plans) - 1:
+        if (part == len(self._part_plans) - 1) if last is None else last:
             for kind, key in self._seg_plan[1][3]:
                 SHADOWS.mark_stale(kind, key)
 
@@ -482,9 +484,18 @@ class CaptionTrainer:
         per_layer = [[p for p in bucket if names[id(p)].startswith(f"bm_enc.encoder.layers.{i}.")] for i in range(n_enc)]
         claimed = {id(p) for lp in per_layer for p in lp}
         per_layer[0] += [p for p in bucket if names[id(p)].startswith("bm_enc.") and id(p) not in claimed]
+        # (the caption embedding last inside its bucket: its backward node is older than the encoder's, so one backward pass
+        # reaches it AFTER the encoder -- the early Adam passes below leave it for the end of the step)
+        late = [p for p in early if names[id(p)].startswith("emb_C.")]
+        early = [p for p in early if not names[id(p)].startswith("emb_C.")] + late
         self.phase_params = [early] + [per_layer[i] for i in reversed(range(n_enc))]
         self.opt = FlatAdam([p for ph in self.phase_params for p in ph], lr=lr, weight_decay=weight_decay)
         self.opt.set_buckets([len(ph) for ph in self.phase_params])
+        # parts of the optimizer pass: [head + fusion stacks | caption embedding | encoder layer N-1 | ... | encoder layer 0]
+        pb = [0, len(early) - len(late), len(early)]
+        for ph in self.phase_params[1:]:
+            pb.append(pb[-1] + len(ph))
+        self.opt.plan_bounds = pb
         self.opt.phased_direct = False      # set by capture() in the one-rank phased mode: gather_grads(bucket) leaves gradients in place
         self.early_params = early
         self.n_enc = n_enc
@@ -494,13 +505,25 @@ class CaptionTrainer:
         # backward.  Measured on MI355X at config 2: 5.88 ms against 5.73 ms for the plain step -- the phase boundaries join
         # every side stream of the backward three times and cost more than the 0.2 ms of Adam they hide; off by default.
         self.phased_adam = os.environ.get("BMHRL_PHASED_ADAM", "0") == "1"
+        # one rank, optional (BMHRL_EARLY_ADAM=1): ONE backward pass, and the optimizer pass of a part starts on a side stream
+        # the moment the backward has gone past it -- a tensor hook on the encoder-layer outputs fires when the layer below
+        # starts its backward, i.e. after every node above it has been launched (the engine runs ready nodes newest first).
+        # Only the Adam stream waits for the backward's streams; the backward itself joins nothing extra (what made the phased
+        # form slower); the caption embedding and the first encoder layer are left for the end.  Bit-identical to the plain
+        # order in deterministic mode (tests/test_split_backward_gpu.py).  Measured on MI355X at config 2, A/B/A/B on one box:
+        # 4.953 / 4.916 ms with it, 4.897 / 4.926 ms without -- nothing: the chip is full during the encoder backward, so the
+        # 0.29 ms of HBM-bound update moved beside it is added to it, not hidden.  Off by default.
+        self.early_adam = os.environ.get("BMHRL_EARLY_ADAM", "0") == "1"
+        self._early_armed = False
+        self._early_pending = {}
+        self._early_done = set()
         self._layer_out = {}
         self._keep_cuts = False
         for i, layer in enumerate(enc_layers):   # (V-stream, A-stream) after layer i: the cut between two backward phases
             # kept only while a phased step is being built (and dropped with its last phase): a layer output held past the end
             # of a step keeps that step's whole autograd graph alive -- memory, and objects of an eager pass that then die in
             # the middle of a later capture (DESIGN.md section 10 "r04")
-            layer.register_forward_hook(lambda mod, inp, out, i=i: self._layer_out.__setitem__(i, out) if self._keep_cuts else None)
+            layer.register_forward_hook(lambda mod, inp, out, i=i: self._on_layer_out(i, out))
         self.modality = "audio_video"
         self.scratch = ScratchState()       # arena + operand pools of this trainer's steps: a captured step keeps their addresses
         self.graph = None
@@ -619,6 +642,7 @@ class CaptionTrainer:
         return s
 
     def _step(self, fs, captions, rl=None):
+        self._early_armed = False
         self._sync_token_weight(captions)
         SEEDS.dev = self.seed_dev
         self._keep_cuts = False
@@ -638,10 +662,68 @@ class CaptionTrainer:
         scale = self.opt.all_reduce()
         adv = captions.is_cuda
         self.opt.step(scale, dev_step_advanced=adv)
+        self._plan_clean = self.scratch.last_spill == 0
         if self.value_net is not None:
             self.vopt.all_reduce()
             self.vopt.step(scale, dev_step_advanced=adv)
         return loss.detach()
+
+    def _step_bucket(self, b):
+        """the optimizer pass of gradient bucket b (phased Adam): bucket 0 is two parts of the table when the caption embedding
+        has its own (FlatAdam.plan_bounds)"""
+        n = len(self.opt._part_plans)
+        parts = [b] if n == self.n_enc + 1 else ([0, 1] if b == 0 else [b + 1])
+        for p in parts:
+            self.opt.step_part(p, 1.0, dev_step_advanced=True, first=(p == 0), last=(p == n - 1))
+
+    def _on_layer_out(self, i, out):
+        if self._keep_cuts:
+            self._layer_out[i] = out
+        if self._early_armed:
+            ts = [t for t in out if torch.is_tensor(t) and t.requires_grad]
+            part = 0 if i == self.n_enc - 1 else self.n_enc - i      # the part whose gradients are complete once layer i starts
+            self._early_pending[part] = len(ts)
+            for t in ts:
+                t.register_hook(lambda g, part=part: self._early_fire(part))
+        return None
+
+    def _early_ok(self) -> bool:
+        o = self.opt
+        plan = o.__dict__.get("_seg_plan")
+        return (self.early_adam and self.device.type == "cuda" and self._world_scale() == 1.0 and not self._split()
+                and o.direct_grads and o.fused_shadows and not o.__dict__.get("_homes", False)
+                and plan is not None and plan[2] is not None and len(o.__dict__.get("_part_plans", ())) == self.n_enc + 2
+                and self.__dict__.get("_plan_clean", False) and self.scratch.last_spill == 0
+                and torch.is_grad_enabled())
+
+    def _adam_stream(self):
+        side = CaptionTrainer._adam_streams.get(self.device)
+        if side is None:
+            side = CaptionTrainer._adam_streams[self.device] = torch.cuda.Stream(device=self.device)
+        return side
+
+    def _early_fire(self, part):
+        """(autograd engine thread, before the first backward node of the encoder layer below `part` runs)"""
+        self._early_pending[part] -= 1
+        if self._early_pending[part] > 0 or part in self._early_done:
+            return None
+        self._early_done.add(part)
+        from .model.bm_hrl_agent import BMEncoderLayer, BMFusionLayer, BMHrlAgent
+        side = self._adam_stream()
+        cur = torch.cuda.current_stream(self.device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        side.wait_stream(cur)
+        for s in (self._main_stream, BMEncoderLayer._side, BMFusionLayer._side, BMHrlAgent._critic_streams.get(self.device)):
+            if s is None or s == cur:
+                continue
+            if capturing:                    # only streams that are part of this capture may be waited for
+                with torch.cuda.stream(s):
+                    if not torch.cuda.is_current_stream_capturing():
+                        continue
+            side.wait_stream(s)
+        with torch.cuda.stream(side):
+            self.opt.step_part(part, 1.0, dev_step_advanced=True, first=(part == 0), last=False)
+        return None
 
     def _backward(self, loss):
         """d loss / d every parameter of the trainer's optimisers, left in p.grad.  torch.autograd.grad rather than
@@ -750,10 +832,10 @@ class CaptionTrainer:
                 for j in range(1, self.n_enc + 1):
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        self.opt.step_part(j - 1, 1.0, dev_step_advanced=True)
+                        self._step_bucket(j - 1)
                     self._graph_body_phase(j)
                 main.wait_stream(side)
-                self.opt.step_part(self.n_enc, 1.0, dev_step_advanced=True)
+                self._step_bucket(self.n_enc)
                 if self.value_net is not None:
                     self.vopt.step(1.0, dev_step_advanced=True)
             elif alone:                       # no all-reduce to leave room for: the optimizer joins the same graph
@@ -813,6 +895,9 @@ class CaptionTrainer:
         SCRATCH.begin_step(self.device, self.scratch, zero_stream=self._zero_stream())
         self._keep_cuts = self._split()
         self._layer_out.clear()
+        self._early_armed = self._early_ok()
+        self._early_pending, self._early_done = {}, set()
+        self._main_stream = torch.cuda.current_stream(self.device)
         trg_in, trg_y, masks = self._head(st, cap)
         if not self.opt.fused_shadows:
             SHADOWS.invalidate()
@@ -869,7 +954,30 @@ class CaptionTrainer:
             SCRATCH.end_step()
 
     def _graph_body_b(self, scale):
+        if self._early_armed:
+            # some parts of the update are already running beside the backward (_early_fire): check that every gradient sat
+            # where their tables read it, then the rest -- the caption embedding, the first encoder layer, anything whose hook
+            # did not fire -- on the step's own stream
+            self._early_armed = False
+            plan = self.opt.__dict__.get("_seg_plan")
+            if self.opt.__dict__.get("_direct_ptrs") is None or plan is None or plan[2] != self.opt._direct_ptrs:
+                raise RuntimeError("early Adam: a gradient is not where the optimizer's table reads it (the weights of the parts "
+                                   "already updated are wrong now); run with BMHRL_EARLY_ADAM=0")
+            torch.cuda.current_stream(self.device).wait_stream(self._adam_stream())
+            n_parts = len(self.opt._part_plans)
+            rest = [p for p in range(n_parts) if p not in self._early_done]
+            for k, p in enumerate(rest):
+                self.opt.step_part(p, 1.0, dev_step_advanced=True, first=(p == 0 and 0 not in self._early_done),
+                                   last=(k == len(rest) - 1))
+            if 0 not in rest and 0 not in self._early_done:
+                raise RuntimeError("early Adam: part 0 never ran")
+            if self.value_net is not None:
+                self.vopt.step(scale, dev_step_advanced=True)
+            return
         self.opt.step(scale, dev_step_advanced=True)              # (the counters moved in the step's first launch: _head)
+        # the table this pass (re)built reads the gradients where THIS pass left them: valid for the next pass when all of them
+        # came out of the scratch arenas (a deterministic bump allocator) -- what _early_ok() asks for
+        self._plan_clean = self.scratch.last_spill == 0
         if self.value_net is not None:
             self.vopt.step(scale, dev_step_advanced=True)
 

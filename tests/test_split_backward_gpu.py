@@ -63,7 +63,8 @@ t.agent.train()
 t.split_backward = sys.argv[2] == "split"
 t.capture(fs, cap, warmup=1)
 losses = [float(t.replay()) for _ in range(3)]
-torch.save({"losses": losses, "flat": t.opt.in_param_order(t.opt.flat).cpu(), "in_place": getattr(t, "grad_elems_in_place", 0), "n": t.opt.n}, sys.argv[1])
+torch.save({"losses": losses, "flat": t.opt.in_param_order(t.opt.flat).cpu(), "in_place": getattr(t, "grad_elems_in_place", 0), "n": t.opt.n,
+            "early": sorted(t._early_done)}, sys.argv[1])
 """
 
 
@@ -166,3 +167,26 @@ def test_a_captured_trainer_survives_a_larger_second_trainer(tmp_path):
     assert all(x == x for x in outs["alone"]["losses"])
     assert outs["alone"]["losses"] == outs["with_b"]["losses"]
     assert torch.equal(outs["alone"]["flat"], outs["with_b"]["flat"])
+
+
+def test_early_adam_passes_change_nothing(tmp_path):
+    """One rank: the optimizer pass of a part starts on a side stream as soon as the backward has gone past it (tensor hooks on
+    the encoder-layer outputs, CaptionTrainer._early_fire).  Deterministic mode: losses and weights after three replays are
+    IDENTICAL to the run with the whole update behind the backward -- a part updated before its gradients were complete, or
+    a weight rewritten while a later backward kernel still reads it, would show."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, BMHRL_DETERMINISTIC="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    outs = {}
+    for early in ("0", "1"):
+        f = tmp_path / f"early_{early}.pt"
+        r = subprocess.run([sys.executable, "-c", _DET_SCRIPT, str(f), "single"], env=dict(base, BMHRL_EARLY_ADAM=early),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[early] = torch.load(f)
+    assert outs["0"]["early"] == [] and outs["1"]["early"] == [0, 2]      # head + fusion stacks, then encoder layer 1
+    assert outs["0"]["losses"] == outs["1"]["losses"] and torch.equal(outs["0"]["flat"], outs["1"]["flat"])
