@@ -455,9 +455,13 @@ def _use_flash(dk: int, Sq: int, Sk: int) -> bool:
     return dk == 256 and Sq >= 128 and Sk <= ops.attention_max_keys()
 
 
-# one-launch few-query memory attention core (csrc/memory_attention.hip): measured slower than the three launches it replaces on
-# the video side (44 vs 35 us), so off by default
-FUSED_MEMATTN = os.environ.get("BMHRL_FUSED_MEMATTN", "0") == "1"
+# one-launch few-query memory attention core (csrc/memory_attention.hip) of the paired fusion stacks.  Alone it is slower than
+# the three launches it replaces on the video side (44 vs 35 us; audio side 28 vs 33) -- it streams the memory from L2 straight
+# into the A operand --, but in the captured step nothing changes (r04 A/B/A/B on one box: 4.907 / 4.913 ms with it, 4.906 /
+# 4.918 without: the caption side is not where the step's time goes) and 16 launches leave the step (384 -> 368 kernels), so it
+# is ON by default since r04.  BMHRL_FUSED_MEMATTN=0: the GEMM path; =2: the audio side (dm = 128) only.
+FUSED_MEMATTN = os.environ.get("BMHRL_FUSED_MEMATTN", "1") in ("1", "2")
+FUSED_MEMATTN_MAXD = 128 if os.environ.get("BMHRL_FUSED_MEMATTN", "1") == "2" else 1 << 30    # "2": the audio side only (dm = 128)
 SMALL_ATTN = os.environ.get("BMHRL_SMALL_ATTN", "1") == "1"      # one-launch attention core for Sq, Sk <= 32 (A/B switch)
 # P / delta / dS of the head-dimension-256 attentions with <= 256 keys in one launch (csrc/attention_bwd256.hip; A/B switch)
 FUSED_SCORES_BWD = os.environ.get("BMHRL_FUSED_SCORES_BWD", "1") == "1"
@@ -1052,7 +1056,7 @@ class PairMemAttnFn(torch.autograd.Function):
                  C_bf16=Qb, ldcb=D, cb_strides=(0, R * D), bias=SHADOWS.bias(*bq), bias_sb2=D)
         # score -> softmax -> context (and dP -> dS -> dQ' in the backward) as ONE launch per direction where the shape allows
         # (csrc/memory_attention.hip: 30 queries against 256 x 1024 / 800 x 128 memories)
-        fused = FUSED_MEMATTN and not self_att and dmp == dm and ops.memory_attention_ok(L, Sk, dm)
+        fused = FUSED_MEMATTN and not self_att and dmp == dm and dm <= FUSED_MEMATTN_MAXD and ops.memory_attention_ok(L, Sk, dm)
         memT, ldt = None, 0
         if fused:
             memb, memT, ldt = SCRATCH.memo_mem(mem, B, Sk, dm)

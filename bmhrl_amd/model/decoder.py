@@ -29,45 +29,45 @@ class TransformerDecoder(nn.Module):
 
 class TransformerDecoderLayer(nn.Module):
 
+    OBJECT_WIDTH = 256          # width of the object detector's query states (model/object_detector.py)
+
     def __init__(self, d_model, nhead, d_model_C, d_goal, dim_feedforward=2048, dropout=0.1, activation="relu",
                  normalize_before=False):
         super().__init__()
-        self.self_attn = MultiheadedAttention(d_model_C, d_model_C, d_model_C, nhead, dropout, d_model)
-        self.multihead_attn = MultiheadedAttention(d_model_C, d_model, d_model, nhead, dropout, d_model)
-        self.detected_attention = MultiheadedAttention(d_model_C, 256, 256, nhead, dropout, d_model)
-        self.linear1 = nn.Linear(d_model_C, dim_feedforward)
-        self.dropout = nn.Dropout(dropout)
+        attend = lambda d_k, d_v: MultiheadedAttention(d_model_C, d_k, d_v, nhead, dropout, d_model)      # noqa: E731
+        # registration order of the reference (:42-62): three attentions, the feed-forward pair, five norms, five dropouts,
+        # the goal attention, the (empty) positional_encoding parameter
+        self.self_attn, self.multihead_attn = attend(d_model_C, d_model_C), attend(d_model, d_model)
+        self.detected_attention = attend(self.OBJECT_WIDTH, self.OBJECT_WIDTH)
+        self.linear1, self.dropout = nn.Linear(d_model_C, dim_feedforward), nn.Dropout(dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model_C)
-        for i in range(1, 6):
-            setattr(self, f"norm{i}", nn.LayerNorm(d_model_C))
-        for i in range(1, 6):
-            setattr(self, f"dropout{i}", nn.Dropout(dropout))
-        self.goal_attention = MultiheadedAttention(d_model_C, d_goal, d_goal, nhead, dropout, d_model)
+        for kind, make in (("norm", lambda: nn.LayerNorm(d_model_C)), ("dropout", lambda: nn.Dropout(dropout))):
+            for i in range(1, 6):
+                setattr(self, f"{kind}{i}", make())
+        self.goal_attention = attend(d_goal, d_goal)
         self.activation = _get_activation_fn(activation)
         self.normalize_before = normalize_before
         self.positional_encoding = nn.Parameter()        # empty in the reference too (checkpoint key of shape (0,))
 
     def forward_post(self, tgt, memory, memory_mask, pos, query_pos, query_mask, goal, goal_mask, goal_pos,
                      detected_objects=None, add_pos=False, obj_mask=None):
-        tr = self.training
-        p = lambda d: d.p if tr else 0.0  # noqa: E731
-        if not add_pos:                                   # query_pos is a PositionalEncoder; causal self attention
-            causal, qk = True, query_pos(tgt)
-        else:                                             # query_pos is a tensor of learned / given positions
-            causal, qk = False, tgt + query_pos
-        branch = self.self_attn(qk, qk, tgt, query_mask, causal=causal)
-        tgt = LayerNormFn.apply(tgt, self.norm1.weight, self.norm1.bias) + F.dropout(branch, p(self.dropout1), tr)
-        tgt = add_norm(tgt, self.multihead_attn(qk, pos(memory), memory, memory_mask), self.norm2, p(self.dropout2), tr)
+        train = self.training
+        rate = lambda d: d.p if train else 0.0  # noqa: E731
+        # queries / keys of the self attention: a PositionalEncoder (causal attention over the caption) or learned positions
+        qk, causal = (tgt + query_pos, False) if add_pos else (query_pos(tgt), True)
+        own = self.self_attn(qk, qk, tgt, query_mask, causal=causal)
+        # (the reference normalises the INPUT and then adds the branch: :77-78)
+        x = LayerNormFn.apply(tgt, self.norm1.weight, self.norm1.bias) + F.dropout(own, rate(self.dropout1), train)
+        x = add_norm(x, self.multihead_attn(qk, pos(memory), memory, memory_mask), self.norm2, rate(self.dropout2), train)
         if goal is not None:
-            branch = self.goal_attention(query_pos(tgt), goal_pos(goal), goal, goal_mask)
-            tgt = add_norm(tgt, branch, self.norm4, p(self.dropout4), tr)
+            x = add_norm(x, self.goal_attention(query_pos(x), goal_pos(goal), goal, goal_mask), self.norm4, rate(self.dropout4), train)
         if detected_objects is not None:
-            branch = self.detected_attention(qk, detected_objects, detected_objects, obj_mask)
-            tgt = add_norm(tgt, branch, self.norm5, p(self.dropout5), tr)
-        ff = feed_forward(tgt, self.linear1, self.linear2, p(self.dropout))
-        return add_norm(tgt, ff, self.norm3, p(self.dropout3), tr)
+            x = add_norm(x, self.detected_attention(qk, detected_objects, detected_objects, obj_mask), self.norm5, rate(self.dropout5),
+                         train)
+        return add_norm(x, feed_forward(x, self.linear1, self.linear2, rate(self.dropout)), self.norm3, rate(self.dropout3), train)
 
     def forward(self, tgt, memory, memory_mask, pos, query_pos, query_mask, goal, goal_mask, goal_pos, add_pos=False,
                 detected_objects=None, obj_mask=None):
+        # (the caller's obj_mask is dropped, as the reference does at :106)
         return self.forward_post(tgt, memory, memory_mask, pos, query_pos, query_mask, goal, goal_mask, goal_pos,
                                  add_pos=add_pos, detected_objects=detected_objects, obj_mask=None)

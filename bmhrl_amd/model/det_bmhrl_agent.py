@@ -17,94 +17,85 @@ from .multihead_attention import MultiheadedAttention
 from .object_detector import ObjectDetect
 
 
+FF_WIDTH, N_LAYERS, N_SCALES = 2048, 3, 3        # fixed in the reference (:19, :24, :76)
+
+
+def _decoder_stack(cfg, width, heads):
+    """three post-norm decoder layers of caption width `width` over the video memory + their final LayerNorm"""
+    layer = TransformerDecoderLayer(cfg.d_model_video, heads, width, cfg.rl_goal_d, FF_WIDTH, cfg.dout_p, "relu", normalize_before=True)
+    return layer, nn.LayerNorm(width)
+
+
 class DetrCaption(nn.Module):
 
     def __init__(self, cfg, train_dataset):
         super().__init__()
-        self.name = "detr_agent"
-        self.att_layers = cfg.rl_att_layers
-        self.device = torch.device(cfg.device) if isinstance(getattr(cfg, "device", None), str) else getattr(cfg, "device", "cpu")
-        self.dim_feedforward = 2048
-        self.dif_work_man_feats = False
-        self.voc_size = train_dataset.trg_voc_size
-        self.d_model = cfg.d_model
-        self.normalize_before = True
-        self.num_layers = 3
+        dev = getattr(cfg, "device", "cpu")
+        d_caps, d_goal, heads, p_drop = cfg.d_model_caps, cfg.rl_goal_d, cfg.rl_att_heads, cfg.dout_p
+        # plain attributes of the reference's constructor (:16-25, :31, :73-76), kept by name
+        self.name, self.att_layers, self.device = "detr_agent", cfg.rl_att_layers, (torch.device(dev) if isinstance(dev, str) else dev)
+        self.dim_feedforward, self.num_layers, self.n_time = FF_WIDTH, N_LAYERS, N_SCALES
+        self.dif_work_man_feats, self.normalize_before, self.teaching_worker = False, True, True
+        self.voc_size, self.d_model, self.n_head = train_dataset.trg_voc_size, cfg.d_model, heads
         self.pre_goal_attention = cfg.pre_goal_attention
-        self.pos_enc = PositionalEncoder(cfg.d_model, cfg.dout_p)
-        self.pos_enc_C = PositionalEncoder(cfg.d_model_caps, cfg.dout_p)
-        self.pos_enc_concat = PositionalEncoder(cfg.d_model_caps + cfg.rl_goal_d, cfg.dout_p)
-        self.pos_enc_goal = PositionalEncoder(cfg.rl_goal_d, cfg.dout_p)
-        self.n_head = cfg.rl_att_heads
-        self.emb_C = VocabularyEmbedder(self.voc_size, cfg.d_model_caps)
+        # --- modules, registered in the reference's order (the state dict lists its keys the same way)
+        for attr, width in (("pos_enc", cfg.d_model), ("pos_enc_C", d_caps), ("pos_enc_concat", d_caps + d_goal), ("pos_enc_goal", d_goal)):
+            setattr(self, attr, PositionalEncoder(width, p_drop))
+        self.emb_C = VocabularyEmbedder(self.voc_size, d_caps)
         self.emb_C.init_word_embeddings(train_dataset.train_vocab.vectors, cfg.unfreeze_word_emb)
-        encoder_layer = TransformerEncoderLayer(cfg.d_model, self.n_head, self.dim_feedforward, cfg.dout_p, "relu",
-                                                normalize_before=self.normalize_before)
-        self.encoder = TransformerEncoder(encoder_layer, self.num_layers, nn.LayerNorm(cfg.d_model), cfg,
-                                          return_intermediate=self.dif_work_man_feats)
-        if not self.pre_goal_attention:
-            worker_layer = manager_layer = TransformerDecoderLayer(cfg.d_model_video, self.n_head, cfg.d_model_caps, cfg.rl_goal_d,
-                                                                   self.dim_feedforward, cfg.dout_p, "relu",
-                                                                   normalize_before=self.normalize_before)
-            worker_norm = manager_norm = nn.LayerNorm(cfg.d_model_caps)
-            self.linear = nn.Linear(cfg.d_model_caps, self.voc_size)
-        else:
-            worker_layer = TransformerDecoderLayer(cfg.d_model_video, self.n_head, cfg.d_model_caps + cfg.rl_goal_d, cfg.rl_goal_d,
-                                                   self.dim_feedforward, cfg.dout_p, "relu", normalize_before=self.normalize_before)
-            manager_layer = TransformerDecoderLayer(cfg.d_model_video, self.n_head, cfg.d_model_caps, cfg.rl_goal_d,
-                                                    self.dim_feedforward, cfg.dout_p, "relu", normalize_before=self.normalize_before)
-            worker_norm = nn.LayerNorm(cfg.d_model_caps + cfg.rl_goal_d)
-            manager_norm = nn.LayerNorm(cfg.d_model_caps)
-            self.linear = nn.Linear(cfg.d_model_caps + cfg.rl_goal_d, self.voc_size)
-        self.worker_decoder = TransformerDecoder(worker_layer, self.num_layers, worker_norm, return_intermediate=False)
-        self.manager_decoder = TransformerDecoder(manager_layer, self.num_layers, manager_norm, return_intermediate=False)
+        self.encoder = TransformerEncoder(TransformerEncoderLayer(cfg.d_model, heads, FF_WIDTH, p_drop, "relu", normalize_before=True),
+                                          N_LAYERS, nn.LayerNorm(cfg.d_model), cfg, return_intermediate=False)
+        # without pre-goal attention worker and manager share ONE layer prototype (cloned per stack) and ONE final LayerNorm
+        # object (:40-44: a checkpoint then holds the same values under worker_decoder.norm.* and manager_decoder.norm.*);
+        # with it the worker's stack is d_goal wider
+        manager_proto = _decoder_stack(cfg, d_caps, heads)
+        worker_proto = _decoder_stack(cfg, d_caps + d_goal, heads) if self.pre_goal_attention else manager_proto
+        self.linear = nn.Linear(worker_proto[1].normalized_shape[0], self.voc_size)
+        self.worker_decoder = TransformerDecoder(worker_proto[0], N_LAYERS, worker_proto[1], return_intermediate=False)
+        self.manager_decoder = TransformerDecoder(manager_proto[0], N_LAYERS, manager_proto[1], return_intermediate=False)
         self.manager_core = nn.Identity()
-        self.manager = Manager(self.device, cfg.d_model_caps, cfg.rl_goal_d, cfg.dout_p, self.manager_core)
+        self.manager = Manager(self.device, d_caps, d_goal, p_drop, self.manager_core)
         self.activation = nn.LogSoftmax(dim=-1)
-        self.goal_norm = nn.LayerNorm(cfg.d_model_caps)
-        self.goal_dropout = nn.Dropout(cfg.dout_p)
-        self.goal_attention = MultiheadedAttention(cfg.d_model_caps, cfg.rl_goal_d, cfg.rl_goal_d, self.n_head, cfg.dout_p, cfg.d_model)
-        self.goal_feature_attention = MultiheadedAttention(cfg.rl_goal_d, cfg.d_model_caps, cfg.d_model_caps, self.n_head,
-                                                           cfg.dout_p, cfg.d_model)
+        self.goal_norm, self.goal_dropout = nn.LayerNorm(d_caps), nn.Dropout(p_drop)
+        self.goal_attention = MultiheadedAttention(d_caps, d_goal, d_goal, heads, p_drop, cfg.d_model)
+        self.goal_feature_attention = MultiheadedAttention(d_goal, d_caps, d_caps, heads, p_drop, cfg.d_model)
         self.manager_modules = [self.manager_core, self.manager, self.manager_decoder]
         self.worker_modules = [self.worker_decoder, self.linear]
-        self.query_embed = nn.Embedding(80, 300)
-        self.teaching_worker = True
-        self.n_time = 3
+        self.query_embed = nn.Embedding(80, 300)                      # (a checkpoint key; the object detector has its own queries)
         self.object_detector = ObjectDetect(cfg, self.voc_size)
-        self.input_proj = nn.ModuleList([nn.Sequential(nn.Conv1d(cfg.d_model, cfg.d_model, kernel_size=3 * i, padding="same"),
-                                                       nn.GroupNorm(32, cfg.d_model)) for i in range(1, self.n_time + 1)])
+        # input projection: kernel sizes 3, 6, 9 over time, each followed by GroupNorm(32)
+        self.input_proj = nn.ModuleList(nn.Sequential(nn.Conv1d(cfg.d_model, cfg.d_model, kernel_size=3 * scale, padding="same"),
+                                                      nn.GroupNorm(32, cfg.d_model)) for scale in range(1, N_SCALES + 1))
         self._reset_parameters()
-        self.critic = SegmentCritic(cfg)
+        self.critic = SegmentCritic(cfg)                              # (after the Xavier pass, as in the reference: it loads its own weights)
         self.critic_score_threshhold = cfg.rl_critic_score_threshhold
-        for proj in self.input_proj:
-            nn.init.xavier_uniform_(proj[0].weight, gain=1)
-            nn.init.constant_(proj[0].bias, 0)
+        for block in self.input_proj:
+            nn.init.xavier_uniform_(block[0].weight, gain=1)
+            nn.init.zeros_(block[0].bias)
+
+    def _checkpoint(self, checkpoint_dir):
+        return f"{checkpoint_dir}/{self.name}.pt"
 
     def save_model(self, checkpoint_dir):
-        torch.save(self.state_dict(), checkpoint_dir + f"/{self.name}.pt")
+        torch.save(self.state_dict(), self._checkpoint(checkpoint_dir))
 
     def load_model(self, checkpoint_dir):
-        self.load_state_dict(torch.load(checkpoint_dir + f"/{self.name}.pt"), strict=False)
+        self.load_state_dict(torch.load(self._checkpoint(checkpoint_dir)), strict=False)
 
-    def _set_module_grads(self, modules, enable):
-        for module in modules:
-            for _, param in module.named_parameters():
-                param.requires_grad = enable
+    def _phase(self, worker: bool):
+        """teach_worker / teach_manager of the reference (:104-117): which side trains, and whether the manager explores"""
+        self.warmstarting, self.teaching_worker = False, worker
+        for modules, on in ((self.worker_modules, worker), (self.manager_modules, not worker)):
+            for module in modules:
+                for param in module.parameters():
+                    param.requires_grad = on
+        self.manager.exploration = not worker
 
     def teach_worker(self):
-        self.warmstarting = False
-        self.teaching_worker = True
-        self._set_module_grads(self.worker_modules, True)
-        self._set_module_grads(self.manager_modules, False)
-        self.manager.exploration = False
+        self._phase(True)
 
     def teach_manager(self):
-        self.warmstarting = False
-        self.teaching_worker = False
-        self._set_module_grads(self.worker_modules, False)
-        self._set_module_grads(self.manager_modules, True)
-        self.manager.exploration = True
+        self._phase(False)
 
     def set_inference_mode(self, inference):
         self.manager.exploration = not inference
@@ -131,15 +122,12 @@ class DetrCaption(nn.Module):
         if self.pre_goal_attention:
             raise NotImplementedError("pre_goal_attention needs the manager branch, which the reference's forward switches off "
                                       "(use_manager = False, model/det_bmhrl_agent.py:177: its own forward raises there)")
-        x_video, _ = x
-        trg = trg.clone()
-        trg[trg == 3] = 1
-        C = self.emb_C(trg)
-        mask = masks["V_mask"]
-        x_video = self.project_input(x_video)
-        classified_words, hs_ob_det, ob_mask = self.object_detector(x_video, mask)
-        memory = self.encoder(x_video, mask, self.pos_enc)
-        worker_feat = self.worker_decoder(C, memory, mask, self.pos_enc, self.pos_enc_C, masks["C_mask"], None, None, None,
-                                          detected_objects=hs_ob_det, obj_mask=ob_mask)
-        pred = torch.log_softmax(LinearFn.apply(worker_feat, self.linear.weight, self.linear.bias, False, 0.0), dim=-1)
-        return pred, worker_feat[:, :, :300], memory, None, None, classified_words
+        frames = self.project_input(x[0])                             # (the audio half of x is not used in this mode)
+        tokens = trg.masked_fill(trg == 3, 1)                         # the end token is embedded as padding (:161-162)
+        v_mask = masks["V_mask"]
+        class_logits, objects, no_object = self.object_detector(frames, v_mask)
+        memory = self.encoder(frames, v_mask, self.pos_enc)
+        feats = self.worker_decoder(self.emb_C(tokens), memory, v_mask, self.pos_enc, self.pos_enc_C, masks["C_mask"], None, None, None,
+                                    detected_objects=objects, obj_mask=no_object)
+        log_probs = torch.log_softmax(LinearFn.apply(feats, self.linear.weight, self.linear.bias, False, 0.0), dim=-1)
+        return log_probs, feats[:, :, :300], memory, None, None, class_logits

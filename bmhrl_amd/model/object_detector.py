@@ -10,35 +10,33 @@ from .blocks import PositionalEncoder
 from .decoder import TransformerDecoder, TransformerDecoderLayer
 from .encoder import TransformerEncoder, TransformerEncoderLayer
 
+WIDTH, QUERIES, HEADS, FF_WIDTH, DEPTH = 256, 100, 4, 2048, 6     # fixed in the reference (:13-14, :19-30)
+
 
 class ObjectDetect(nn.Module):
 
     def __init__(self, cfg, voc_size):
         super().__init__()
-        self.d_model = cfg.d_model
-        hidden_dim = 256
-        num_queries = 100
-        self.num_classes = voc_size + 1
-        self.class_embed = nn.Linear(hidden_dim, self.num_classes)
-        self.query_embed = nn.Embedding(num_queries, hidden_dim)
-        self.pos_enc = PositionalEncoder(hidden_dim, cfg.dout_p)
-        self.input_projection = nn.Linear(self.d_model, hidden_dim)
-        encoder_layer = TransformerEncoderLayer(hidden_dim, 4, 2048, cfg.dout_p, "relu", normalize_before=True)
-        self.encoder = TransformerEncoder(encoder_layer, 6, nn.LayerNorm(hidden_dim), cfg, return_intermediate=False)
-        decoder_layer = TransformerDecoderLayer(hidden_dim, 4, hidden_dim, cfg.rl_goal_d, 2048, cfg.dout_p, "relu",
-                                                normalize_before=True)
-        self.linear = nn.Linear(hidden_dim, voc_size)                  # (never applied by the reference either)
-        self.decoder = TransformerDecoder(decoder_layer, 6, nn.LayerNorm(hidden_dim), return_intermediate=False)
+        p_drop = cfg.dout_p
+        self.d_model, self.num_classes = cfg.d_model, voc_size + 1          # the extra class is "no object"
+        # (modules are registered in the reference's order: the state dict lists its keys the same way)
+        self.class_embed = nn.Linear(WIDTH, self.num_classes)
+        self.query_embed = nn.Embedding(QUERIES, WIDTH)
+        self.pos_enc = PositionalEncoder(WIDTH, p_drop)
+        self.input_projection = nn.Linear(cfg.d_model, WIDTH)
+        self.encoder = TransformerEncoder(TransformerEncoderLayer(WIDTH, HEADS, FF_WIDTH, p_drop, "relu", normalize_before=True),
+                                          DEPTH, nn.LayerNorm(WIDTH), cfg, return_intermediate=False)
+        self.linear = nn.Linear(WIDTH, voc_size)                             # in the checkpoint; nobody applies it
+        self.decoder = TransformerDecoder(TransformerDecoderLayer(WIDTH, HEADS, WIDTH, cfg.rl_goal_d, FF_WIDTH, p_drop, "relu",
+                                                                  normalize_before=True),
+                                          DEPTH, nn.LayerNorm(WIDTH), return_intermediate=False)
 
-    def forward(self, samples, mask):
+    def forward(self, feats, key_mask):
         """reference :33-46 -> (class logits (B, 100, V + 1), detached query states (B, 100, 256), "no object" mask (B, 100))"""
-        samples = LinearFn.apply(samples, self.input_projection.weight, self.input_projection.bias, False, 0.0)
-        bs = samples.shape[0]
-        memory = self.encoder(samples, mask, self.pos_enc)
-        query_pos = self.query_embed.weight.unsqueeze(0).repeat(bs, 1, 1)
-        tgt = torch.zeros_like(query_pos)
-        hs = self.decoder(tgt, memory, mask, self.pos_enc, query_pos, None, None, None, None, add_pos=True)
-        predicted_words = LinearFn.apply(hs, self.class_embed.weight, self.class_embed.bias, False, 0.0)
-        # argmax of the softmax == argmax of the logits (:43)
-        attention_mask = torch.argmax(predicted_words, -1) == (self.num_classes - 1)
-        return predicted_words, hs.detach(), attention_mask.detach()
+        x = LinearFn.apply(feats, self.input_projection.weight, self.input_projection.bias, False, 0.0)
+        mem = self.encoder(x, key_mask, self.pos_enc)
+        queries = self.query_embed.weight.expand(x.shape[0], QUERIES, WIDTH).contiguous()     # one copy of the table per sample
+        states = self.decoder(torch.zeros_like(queries), mem, key_mask, self.pos_enc, queries, None, None, None, None, add_pos=True)
+        logits = LinearFn.apply(states, self.class_embed.weight, self.class_embed.bias, False, 0.0)
+        no_object = logits.argmax(-1) == self.num_classes - 1                # (arg-max of the soft-max, :43, is that of the logits)
+        return logits, states.detach(), no_object.detach()

@@ -342,10 +342,13 @@ def test_value_functions_match_the_reference(golden):
 
 
 @pytest.mark.parametrize("tiny", [True, False])
-def test_paired_fusion_stacks_equal_separate_stacks(dev, tiny):
+def test_paired_fusion_stacks_equal_separate_stacks(dev, tiny, monkeypatch):
     """functional.PairMemAttnFn (worker and manager fusion stacks in one set of launches) against the two stacks run one
     after the other: same log-probs, features and every gradient (same kernels on the same numbers; what differs is the
-    arrival order of the fp32 atomics of split-K weight gradients and column sums)."""
+    arrival order of the fp32 atomics of split-K weight gradients and column sums).  The one-launch memory attention core
+    exists in the paired form only, so it is switched off here (tests/test_blocks_gpu.py compares it with the GEMM path)."""
+    from bmhrl_amd import functional
+    monkeypatch.setattr(functional, "FUSED_MEMATTN", False)
     from bmhrl_amd.loss.label_smoothing import LabelSmoothing
     from bmhrl_amd.model.bm_hrl_agent import BMHrlAgent
     from bmhrl_amd.model.masking import make_masks
