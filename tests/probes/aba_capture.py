@@ -1,3 +1,5 @@
+"""Probe behind tests/test_split_backward_gpu.py::test_a_captured_trainer_survives_a_larger_second_trainer with progress prints and
+variants: argv[1] = output file (unused), argv[2] = alone | with_b | with_b_nostep | with_b_sidestep | with_b_noa (DESIGN.md section 10 "r04")."""
 import faulthandler; faulthandler.enable()
 import sys, torch
 from bmhrl_amd import synthetic as syn
