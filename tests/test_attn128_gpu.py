@@ -153,3 +153,36 @@ def test_shared128_fused_backward_matches_torch_autograd(B, H, Sq, Sk):
     ops.attention_shared128_bwd(Qp, X, dCx, rmax, rsum, delta, None if False else mask, Sk, dQp, None, False, B, H, Sq, Sk, scale,
                                 H * 128, 128, H * 128, H * 128)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk", [(16, 4, 256, 800), (2, 4, 200, 130), (8, 4, 70, 200), (3, 2, 256, 800), (2, 4, 64, 20)])
+def test_two_heads_per_wave_form_matches_the_default_kernel(B, H, Sq, Sk):
+    """bmhrl_attention_config(128, 14): the r04 kernel in which one wave carries two heads of its query rows over four key
+    splits (csrc/attention_pair.h; opt-in, BMHRL_ATTN_PAIR=1) against the shipped kernel on the same inputs -- contexts to bf16
+    rounding, log-sum-exp of the statistics to 2e-3; shapes the form does not serve (odd head counts) fall back by themselves."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from bmhrl_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + Sq + Sk)
+    Qp = (0.5 * torch.randn(B, Sq, H, 128, generator=g)).to(dev).to(torch.bfloat16)
+    X = torch.randn(B, Sk, 128, generator=g).to(dev).to(torch.bfloat16)
+    mask = torch.ones(B, Sk, dtype=torch.bool, device=dev)
+    mask[0, Sk - 5:] = False
+    mask[B - 1, :] = False                         # fully masked sample: uniform attention
+    scale = 1.0 / math.sqrt(256)
+    out = {}
+    try:
+        for code in (0, 14):
+            _lib.check(_lib.load().bmhrl_attention_config(128, code), "bmhrl_attention_config")
+            ctx = torch.empty(B, Sq, H, 128, dtype=torch.bfloat16, device=dev)
+            rmax = torch.empty(B, H, Sq, device=dev)
+            rsum = torch.empty(B, H, Sq, device=dev)
+            ops.attention_shared128_fwd(Qp, X, ctx, rmax, rsum, mask, Sk, B, H, Sq, Sk, scale, H * 128, 128, H * 128)
+            torch.cuda.synchronize()
+            out[code] = (ctx.float(), rmax + torch.log(rsum))
+    finally:
+        _lib.load().bmhrl_attention_config(128, 0)
+    assert float((out[14][0] - out[0][0]).abs().max()) < 2e-2 * float(out[0][0].abs().max())
+    live = out[0][1] > -1e8
+    assert float((out[14][1][live] - out[0][1][live]).abs().max()) < 2e-3
