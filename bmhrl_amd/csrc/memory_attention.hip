@@ -17,10 +17,13 @@
 //            tiles are dealt to the waves, the rows leave through an LDS image as whole 16-byte pieces
 //
 // The memory is read straight from L2 into the A operand (each (sample, head) streams it once per pass: 2 x 512 KB for the video
-// side), and that is what bounds it.  MEASURED (tests/bench_memattn.py, r03): video side 44 us forward / 46 us backward against
-// 35 us for the three launches it replaces, audio side 28 / 31 against 33 -- the stream runs at what eight waves keep in
-// flight from registers.  Until the memory tiles go through LDS with direct-to-LDS loads (as in attention_fwd.h) the GEMM path
-// stays the default: functional.FUSED_MEMATTN / BMHRL_FUSED_MEMATTN=1 selects this kernel (parity: tests/test_memory_attention_gpu.py).
+// side).  MEASURED alone (tests/bench_memattn.py): r03 video side 44 us forward / 46 us backward against 35 us for the three
+// launches it replaces, audio side 28 / 31 against 33; r04 with the XCD-aware block map below (all heads and both stacks of a
+// sample on one XCD: the memory leaves the Infinity Cache once instead of four times) 38.8 / 44.2 us and 23.0 / 24.6 us, the
+// GEMM path 29.9 / 33.2 us.  Deeper unrolling of the load streams (32 loads in flight per wave) changed nothing.  In the captured
+// step the two paths are indistinguishable (4.907 vs 4.906 - 4.918 ms) and this one is 16 launches shorter, so it is the
+// default since r04 (functional.FUSED_MEMATTN; BMHRL_FUSED_MEMATTN=0 selects the GEMM path; parity:
+// tests/test_memory_attention_gpu.py, tests/test_blocks_gpu.py).
 #include "../../include/bmhrl_hip.h"
 #include "common.h"
 
@@ -40,6 +43,7 @@ struct MemAttnArgs {
   const uint8_t* mask; long mask_sb;    // + b2 * mask_sb + key
   int nb, H, L, Sk, Skp, dm;
   float scale;
+  int xcd_map;                          // 1: block -> (sample, head) through the XCD-aware map (B2 a multiple of 8)
 };
 
 __device__ __forceinline__ int ma_key_of_row(int rho) {
@@ -51,7 +55,18 @@ __global__ __launch_bounds__(MA_THREADS) void mem_attn_kernel(const MemAttnArgs 
   __shared__ __attribute__((aligned(16))) bf16_t Xs[32 * (MA_MAXD + MA_PAD)];   // X rows; later the output image
   __shared__ __attribute__((aligned(16))) bf16_t Es[32 * (MA_MAXK + MA_PAD)];   // P / dS rows [q][key]
   __shared__ float red[MA_WAVES][32][2];
-  const int b2 = blockIdx.x / p.H, hd = blockIdx.x % p.H;
+  // workgroups are dealt round-robin over the 8 XCDs (private L2s).  All heads of a sample -- and the same sample of the other
+  // fusion stack (b2 % nb) -- stream the SAME memory: give them block ids that differ by multiples of 8 so that one L2 fetches
+  // it once (with the plain order the four heads of a sample sit on four XCDs: the memory came out of the Infinity Cache 4 x)
+  int b2, hd;
+  if (p.xcd_map) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    hd = idx % p.H;
+    b2 = xcd + 8 * (idx / p.H);
+  } else {
+    b2 = blockIdx.x / p.H;
+    hd = blockIdx.x % p.H;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int dm = p.dm, ldxs = dm + MA_PAD, ldes = p.Skp + MA_PAD;
@@ -274,6 +289,8 @@ extern "C" int bmhrl_memory_attention(int32_t backward, const void* X, int64_t l
   a.memT = (const bf16_t*)mem_t; a.memT_sb = mem_t_sb; a.ldt = ldt;
   a.PD = (bf16_t*)PD; a.pd_row = pd_row; a.pd_slot = pd_slot; a.Y = (bf16_t*)Y; a.ldy = ldy;
   a.mask = mask; a.mask_sb = mask_sb; a.nb = n_mem; a.H = H; a.L = L; a.Sk = Sk; a.Skp = Skp; a.dm = dm; a.scale = scale;
+  static const bool plain = getenv("BMHRL_MEMATTN_PLAINMAP") != nullptr;      // (A/B switch)
+  a.xcd_map = (B2 % 8 == 0 && !plain) ? 1 : 0;
   dim3 grid((unsigned)(B2 * H)), block(MA_THREADS);
   if (backward) hipLaunchKernelGGL(mem_attn_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(mem_attn_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
