@@ -34,8 +34,28 @@ struct GemmArgs {
   float dropout_p; uint64_t seed; const uint64_t* seed_dev; long drop_sb1, drop_sb2, drop_sm;
   float* colsum; long cs_sb2, bias_sb2, cs_sb1, bias_sb1;
   int tiles_m, splits, k_per_split, vec_ok, dbg, fast_bf16, fast_pd, tiles_mn;
+  int xcd_chunk, group_m;   // tile order of the direct-to-LDS kernel: see tile_of_block (0, 0: m fastest, the plain order)
   float* split_ws;          // ordered K split: the splits' partial tiles [batch][split][M][N] (summed by splitk_reduce_kernel)
 };
+
+// Which output tile a workgroup of the direct-to-LDS kernel owns.  Workgroups are dealt round-robin over the 8 XCDs, each with
+// its own L2.  Plain order (m fastest): an XCD gets every eighth row panel and EVERY column panel -- a 16 x 16 grid of tiles puts
+// 2 A panels and 16 B panels through each L2.  With xcd_chunk (= tiles / 8, when that divides) an XCD owns a contiguous run of
+// the tile sequence, and the sequence itself walks groups of group_m row panels across all columns, so the run is a near-square
+// patch of the output: 4 x 8 tiles = 4 + 8 panels instead of 2 + 16.
+__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int bx, int& tile_m, int& tile_n) {
+  if (p.xcd_chunk) bx = (bx & 7) * p.xcd_chunk + (bx >> 3);
+  if (p.group_m) {
+    const int tiles_n = p.tiles_mn / p.tiles_m, per_group = p.group_m * tiles_n;
+    const int g = bx / per_group, r = bx - g * per_group;
+    const int gm = min(p.group_m, p.tiles_m - g * p.group_m);        // (the last group may be short)
+    tile_n = r / gm;
+    tile_m = g * p.group_m + (r - tile_n * gm);
+  } else {
+    tile_m = bx % p.tiles_m;
+    tile_n = bx / p.tiles_m;
+  }
+}
 
 constexpr int BK = 64;
 
@@ -660,7 +680,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmArgs p) {
   const int r32 = lane & 31, h = lane >> 5;
   const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int bz = blockIdx.z, b1 = bz / p.batch2, b2 = bz % p.batch2;
-  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  int tile_m, tile_n;
+  tile_of_block(p, (int)blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A + b1 * p.a_sb1 + b2 * p.a_sb2);
   const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B + b1 * p.b_sb1 + b2 * p.b_sb2);
@@ -1095,6 +1116,23 @@ hipError_t launch(const GemmArgs& a, int a_trans, int b_trans, int batch, int sp
   p.tiles_m = (a.M + BM - 1) / BM;
   const int tiles_n = (a.N + BN - 1) / BN;
   p.tiles_mn = p.tiles_m * tiles_n;
+  p.xcd_chunk = p.group_m = 0;
+  {
+    // XCD-aware tile order (BMHRL_GEMM_XCD=1, tuning switch, off): patches of about sqrt(tiles / 8) row panels.  Measured r04
+    // (tests/kbench/gemm_xcd_ab.sh): alone +-5 % either way (V qkv 36.8 -> 34.8 us, A qkv 32.8 -> 30.9, V qkv dX 45.8 -> 43.8,
+    // V dW 21.1 -> 20.3; V qkv dW 48.1 -> 50.3, 8192^3 998 -> 1050 us); the captured step 4.873 / 4.899 ms without, 4.882 /
+    // 4.868 with: the L2 fill traffic these GEMMs cause is not what limits them.
+    static const int xcd = getenv("BMHRL_GEMM_XCD") ? atoi(getenv("BMHRL_GEMM_XCD")) : 0;
+    if (xcd && p.tiles_mn % 8 == 0 && p.tiles_mn >= 64 && tiles_n >= 2) {
+      const int chunk = p.tiles_mn / 8;
+      int g = 1;
+      while ((g + 1) * (g + 1) <= chunk && g + 1 <= p.tiles_m) ++g;     // floor(sqrt(chunk)), at most tiles_m
+      while (g > 1 && chunk % g != 0) --g;                               // whole patches: g rows x chunk / g columns
+      if (xcd >= 2) g = xcd <= p.tiles_m ? xcd : p.tiles_m;              // (forced group height)
+      p.xcd_chunk = chunk;
+      p.group_m = g;
+    }
+  }
   p.splits = splits;
   p.dbg = getenv("BMHRL_GEMM_DBG") ? atoi(getenv("BMHRL_GEMM_DBG")) : 0;
   const int ktiles = (a.K + BK - 1) / BK;
