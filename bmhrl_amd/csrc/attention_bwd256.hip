@@ -36,7 +36,7 @@ struct PsArgs {
   bf16_t* P; bf16_t* dS; long ldp;              // (B, H, Sq, ldp), ldp = pad8(Sk)
   int B, H, Sq, Sk;
   float scale;
-  int q_tiles;
+  int q_tiles, xcd_map;
 };
 
 constexpr int PS_STAGE = 2 * 32 * 512;            // K tile + V tile
@@ -53,7 +53,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ps256_kernel(const PsArgs p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, h = lane >> 5;
-  const int qt = blockIdx.x % p.q_tiles, bh = blockIdx.x / p.q_tiles;
+  // the q-tiles of one (sample, head) stream the same K / V: block ids that differ by multiples of 8 share an XCD (one L2)
+  int qt, bh;
+  if (p.xcd_map) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q1 = idx / p.q_tiles;
+    bh = xcd + 8 * q1;
+    qt = idx - q1 * p.q_tiles;
+  } else {
+    qt = blockIdx.x % p.q_tiles;
+    bh = blockIdx.x / p.q_tiles;
+  }
   const int b = bh / p.H, hd = bh - b * p.H;
   const int q_row = qt * 128 + wave * 32 + r32;
   const bool q_ok = q_row < p.Sq;
@@ -221,6 +230,7 @@ extern "C" int bmhrl_attention_bwd_scores256(const void* Q, int64_t ldq, const v
   a.dO = (const bf16_t*)dO; a.lddo = lddo; a.row_max = row_max; a.row_sum = row_sum; a.mask = mask; a.mask_sb = mask_sb;
   a.P = (bf16_t*)P; a.dS = (bf16_t*)dS; a.ldp = ldp; a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale;
   a.q_tiles = (Sq + 127) / 128;
+  a.xcd_map = ((B * H) % 8 == 0 && getenv("BMHRL_PS256_PLAINMAP") == nullptr) ? 1 : 0;
   const dim3 grid((unsigned)(B * H * a.q_tiles)), block(256);
   switch ((Sk + 31) / 32) {
     case 1: hipLaunchKernelGGL(attn_bwd_ps256_kernel<1>, grid, block, 0, (hipStream_t)stream, a); break;
