@@ -89,3 +89,72 @@ def test_token_weighted_ranks_equal_global_normalisation():
     ((x @ w).pow(2).sum(-1).sum() / x.shape[0]).backward()
     opt.gather_grads(); opt.step()
     assert torch.allclose(opt.flat, out[0][0], atol=1e-6)
+
+
+def _homes_params():
+    torch.manual_seed(0)
+    shapes = [(8, 4), (4,), (8, 4), (4,), (12, 4), (16,)]          # w_a, b_a, w_b, b_b (stacked pair) | w_c, lone
+    return [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+
+
+def _homes_grads(step, rank):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return torch.randn(16, 4, generator=g), torch.randn(8, generator=g), torch.randn(12, 4, generator=g), torch.randn(16, generator=g)
+
+
+def _homes_worker(rank, world, port, out):
+    """two ranks; after FlatAdam.adopt_homes the "kernels" (here: plain copies) write the gradients straight into the bucket runs
+    the allocator hands out, the buckets are all-reduced one by one and Adam runs on the bucket -- no gather copy of those"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bmhrl_amd.functional import ScratchState
+    from bmhrl_amd.train import FlatAdam
+    ps = _homes_params()
+    opt = FlatAdam(ps, lr=1e-2)
+    opt.set_buckets([4, 2])
+    st = ScratchState()
+    # the recording pass: one stacked allocation for [w_a; w_b], one for [b_a; b_b], one for w_c; `lone` comes from elsewhere
+    sw, sb, wc, lone = _homes_grads(0, rank)
+    st.log = [(0, 0, 64, sw.data_ptr(), sw), (0, 64, 8, sb.data_ptr(), sb), (1, 0, 48, wc.data_ptr(), wc)]
+    for p, g in zip(ps, (sw[:8], sb[:4], sw[8:], sb[4:], wc, lone)):
+        p.grad = g
+    assert opt.adopt_homes(st) == 64 + 8 + 48
+    copied = 0
+    for step in range(3):
+        sw, sb, wc, lone = _homes_grads(step, rank)
+        opt.grad.zero_()                                     # (StepScratch.begin_step does this for the home buckets)
+        st.homes[(0, 0)].copy_(sw.reshape(-1)); st.homes[(0, 64)].copy_(sb); st.homes[(1, 0)].copy_(wc.reshape(-1))
+        for p in ps[:5]:
+            k = [i for i, q in enumerate(opt.params) if q is p][0]
+            p.grad = opt.grad_views[k]                       # what the step's allocator handed to the producing kernel
+        ps[5].grad = lone
+        before = opt.grad.clone()
+        works = []
+        for part in (0, 1):
+            opt.gather_grads(part)
+            works.append(opt.all_reduce_part(part))
+        copied += int((opt.grad != before).sum())            # only `lone` (16 elements) may have been copied in
+        for w in works:
+            if w is not None:
+                w.wait()
+        opt.step(1.0 / world)
+    out[rank] = (opt.in_param_order(opt.flat).clone(), copied)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_gradients_produced_in_the_bucket_equal_one_process():
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_homes_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.equal(out[0][0], out[1][0]) and out[0][1] <= 3 * 16
+    from bmhrl_amd.train import FlatAdam
+    ps = _homes_params()
+    opt = FlatAdam(ps, lr=1e-2)
+    for step in range(3):
+        per_rank = [_homes_grads(step, r) for r in range(world)]
+        sw, sb, wc, lone = (sum(t) / world for t in zip(*per_rank))
+        for p, g in zip(ps, (sw[:8], sb[:4], sw[8:], sb[4:], wc, lone)):
+            p.grad = g.clone()
+        opt.gather_grads(); opt.step()
+    assert torch.allclose(opt.in_param_order(opt.flat), out[0][0], atol=1e-6)
