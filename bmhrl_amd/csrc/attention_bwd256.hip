@@ -74,16 +74,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ps256_kernel(const PsArgs p) 
   const char* __restrict__ Kb = reinterpret_cast<const char*>(p.K + (long)b * p.Sk * p.ldk + hd * DK);
   const char* __restrict__ Vb = reinterpret_cast<const char*>(p.V + (long)b * p.Sk * p.ldv + hd * DK);
   const int hi = lane >> 5, pch = lane & 31;
+  // per-lane byte offsets of the four pieces of a tile, fixed for the launch (a row's swizzle depends on row & 15 only, which
+  // a tile step of 32 rows leaves alone): tile t adds t * 32 rows; rows behind the last key re-read key Sk - 1 (P is 0 there)
+  const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
+  int srow[4];
+  unsigned sch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    srow[i] = wave * 8 + 2 * i + hi;
+    sch[i] = (unsigned)((pch ^ (srow[i] & 15)) << 4);
+  }
   auto stage = [&](const int t, const int st) {
     bf16_t* kd = reinterpret_cast<bf16_t*>(smem_raw + st * PS_STAGE) + wave * 8 * DK;
     bf16_t* vd = kd + 32 * DK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = wave * 8 + 2 * i + hi;
-      const int key = min(32 * t + row, p.Sk - 1);                    // (rows behind the last key: finite values, P is 0 there)
-      const int lc = pch ^ (row & 15);
-      glds16<0>(Kb + (long)key * p.ldk * 2 + (lc << 4), kd + i * 2 * DK);
-      glds16<0>(Vb + (long)key * p.ldv * 2 + (lc << 4), vd + i * 2 * DK);
+      const unsigned key = (unsigned)min(32 * t + srow[i], p.Sk - 1);
+      glds16<0>(Kb + (key * ldk2 + sch[i]), kd + i * 2 * DK);
+      glds16<0>(Vb + (key * ldv2 + sch[i]), vd + i * 2 * DK);
     }
   };
   stage(0, 0);
@@ -150,36 +158,37 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ps256_kernel(const PsArgs p) 
   });
 
   // ---- softmax backward on the lane's own query row.  Key of register r of tile t: 32 t + 4 h + (r & 3) + 8 (r >> 2).
-  unsigned keepw[nt];                        // keep bits of the 32 keys of tile t (wave-uniform)
-#pragma unroll
-  for (int t = 0; t < nt; ++t) keepw[t] = __builtin_amdgcn_readfirstlane(s_keep[t]);
+  // The per-element work is kept to: one fma (score -> exponent), one bit-field extract + one bit select (masked keys take the
+  // exponent of the fill value), exp2, one multiply, the bf16 rounding, one fma for the row term; then subtract + two multiplies
+  // for dS.  No per-key test is needed for dS: a masked key of a row that has any unmasked key has P = exp2(-1.4e9) = 0
+  // exactly, and a fully masked row (row max == the fill value: the forward keeps it exact) gets the factor 0 as a whole.
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c1 = p.scale * LOG2E, mneg = -m_row * LOG2E;
+  const float arg_masked = (NEG_MASK - m_row) * LOG2E;              // 0 for a fully masked row: uniform attention
+  const float ds_scale = m_row < -5e8f ? 0.f : p.scale;             // masked_fill passes no gradient
+  const unsigned tail_valid = (p.Sk & 31) ? ((1u << (p.Sk & 31)) - 1u) >> (4 * h) : 0xffffffffu;   // keys < Sk of the last tile
   float delta = 0.f;
 #pragma unroll
   for (int t = 0; t < nt; ++t) {
-    {
+    const unsigned kw = (unsigned)__builtin_amdgcn_readfirstlane(s_keep[t]) >> (4 * h);     // this lane's keys from bit 0
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
-        const bool keep = (keepw[t] >> (4 * h + (r & 3) + 8 * (r >> 2))) & 1u;
-        const float x = keep ? s[t][r] * p.scale : NEG_MASK;
-        float pr = key < p.Sk ? __expf(x - m_row) * il_row : 0.f;
-        pr = (float)(bf16_t)pr;                                        // the value the dV product reads
-        s[t][r] = pr;
-        delta += pr * dpv[t][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2);
+      const int keep = -(int)((kw >> c) & 1u);                                       // 0 / -1 (v_bfe_i32)
+      const float a_k = fmaf(s[t][r], c1, mneg);
+      const float arg = __int_as_float((__float_as_int(a_k) & keep) | (__float_as_int(arg_masked) & ~keep));
+      float pr = __builtin_amdgcn_exp2f(arg) * il_row;
+      if (t == nt - 1) pr = ((tail_valid >> c) & 1u) ? pr : 0.f;                     // rows behind the last key (clamped loads)
+      pr = (float)(bf16_t)pr;                                                        // the value the dV product reads
+      s[t][r] = pr;
+      delta = fmaf(pr, dpv[t][r], delta);
     }
   }
   delta += __shfl_xor(delta, 32, 64);       // the two 32-lane halves hold disjoint keys of the same query row
 #pragma unroll
-  for (int t = 0; t < nt; ++t) {
-    {
+  for (int t = 0; t < nt; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool keep = (keepw[t] >> (4 * h + (r & 3) + 8 * (r >> 2))) & 1u;
-        dpv[t][r] = keep ? s[t][r] * (dpv[t][r] - delta) * p.scale : 0.f;   // no gradient through masked_fill
-      }
-    }
-  }
+    for (int r = 0; r < 16; ++r) dpv[t][r] = (s[t][r] * ds_scale) * (dpv[t][r] - delta);
 
   // ---- P, then dS: bf16 rows through the wave's padded LDS image, whole 16-byte pieces of contiguous rows to global
   char* img = smem_raw + wave * 32 * PS_ROWB;
@@ -224,6 +233,7 @@ extern "C" int bmhrl_attention_bwd_scores256(const void* Q, int64_t ldq, const v
   BMHRL_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 256);
   BMHRL_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldp % 8 == 0 && ldp >= Sk && ldp <= 256);
   BMHRL_CHECK_ARG(ldq >= (int64_t)H * 256 && ldk >= (int64_t)H * 256 && ldv >= (int64_t)H * 256 && lddo >= (int64_t)H * 256);
+  BMHRL_CHECK_ARG((int64_t)Sk * ldk * 2 < (1ll << 31) && (int64_t)Sk * ldv * 2 < (1ll << 31));   // 32-bit lane offsets
   BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)dO | (uintptr_t)P | (uintptr_t)dS) & 15) == 0);
   PsArgs a;
   a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
