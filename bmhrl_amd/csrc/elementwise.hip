@@ -1014,6 +1014,40 @@ __global__ void adam_segments_kernel(const int64_t* __restrict__ seg, int n_seg,
     return;
   }
   if ((cols & 3) == 0 && (ldd & 3) == 0 && (off & 3) == 0 && (e[1] & 7) == 0 && (e[6] & 15) == 0) {     // 16-byte accesses of the four arrays
+    if (end - base == SEG_ELEMS_PER_BLOCK && blockDim.x * 16 == SEG_ELEMS_PER_BLOCK) {
+      // a whole block (the usual case): all sixteen 16-byte loads of a thread are requested before the first result is used --
+      // the pass is a pure stream, what bounds it is the number of bytes in flight
+      f32x4 gv[4], pv[4], mv[4], vv[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const long i = base + 4 * threadIdx.x + it * (SEG_ELEMS_PER_BLOCK / 4);
+        gv[it] = *reinterpret_cast<const f32x4*>(g + off + i);
+        pv[it] = *reinterpret_cast<const f32x4*>(p + off + i);
+        mv[it] = *reinterpret_cast<const f32x4*>(m + off + i);
+        vv[it] = *reinterpret_cast<const f32x4*>(v + off + i);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const long i = base + 4 * threadIdx.x + it * (SEG_ELEMS_PER_BLOCK / 4);
+        f32x4 pn;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float gi = gv[it][j] * gscale;
+          if (wd != 0.f) gi += wd * pv[it][j];
+          mv[it][j] = b1 * mv[it][j] + (1.f - b1) * gi;
+          vv[it][j] = b2 * vv[it][j] + (1.f - b2) * gi * gi;
+          pn[j] = pv[it][j] - step_size * mv[it][j] / (sqrtf(vv[it][j]) / bc2_sqrt + eps);
+          o[j] = (bf16_t)pn[j];
+        }
+        *reinterpret_cast<f32x4*>(m + off + i) = mv[it];
+        *reinterpret_cast<f32x4*>(v + off + i) = vv[it];
+        *reinterpret_cast<f32x4*>(p + off + i) = pn;
+        const long r = i / cols, c = i - r * cols;
+        *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = o;
+      }
+      return;
+    }
     for (long i = base + 4 * threadIdx.x; i < end; i += 4 * blockDim.x) {
       f32x4 gv = *reinterpret_cast<const f32x4*>(g + off + i);
       const f32x4 pv = *reinterpret_cast<const f32x4*>(p + off + i);
