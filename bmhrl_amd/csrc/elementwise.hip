@@ -317,6 +317,33 @@ __global__ void add_posenc_kernel(const float* __restrict__ a, const float* __re
   }
 }
 
+// the same, four columns per thread (D % 4 == 0, 16-byte aligned operands): the video stream's 4 M elements are the first launch
+// of the encoder chain -- 23.7 us one element at a time with three 64-bit divisions each.  The dropout mask is the per-element
+// hash of the scalar form (same bits for the same (seed, index)).
+__global__ void add_posenc_vec4_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ pe,
+                                       float* __restrict__ out, bf16_t* __restrict__ ob, long ldob, int S, int D4, long total4,
+                                       float p, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = seed0 + ((p > 0.f && seed_dev) ? seed_dev[0] : 0ull);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / D4;
+    const int c4 = (int)(i - row * D4), s = (int)(row % S);
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+    if (b) v += reinterpret_cast<const f32x4*>(b)[i];
+    v += reinterpret_cast<const f32x4*>(pe)[(long)s * D4 + c4];
+    if (p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= dropout_scale(p, seed, (uint64_t)(4 * i + j));
+    }
+    reinterpret_cast<f32x4*>(out)[i] = v;
+    if (ob) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x4*>(ob + row * ldob + 4 * c4) = o;
+    }
+  }
+}
+
 __global__ void embed_posenc_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ tok2, float mix,
                                     const float* __restrict__ table, const float* __restrict__ pe, float* __restrict__ emb,
                                     float* __restrict__ out, int L, int D, long total, float scale, float p, uint64_t seed0,
@@ -1339,6 +1366,12 @@ extern "C" int bmhrl_add_posenc(const float* a, const float* b, const float* pe,
                                 bmhrl_stream_t stream) {
   BMHRL_CHECK_ARG(a && pe && out && B > 0 && S > 0 && D > 0);
   const long total = (long)B * S * D;
+  const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)pe | (uintptr_t)out;
+  if (D % 4 == 0 && (al & 15) == 0 && (!out_bf16 || (ldob % 4 == 0 && ((uintptr_t)out_bf16 & 7) == 0))) {
+    hipLaunchKernelGGL(add_posenc_vec4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, S_(stream), a, b, pe, out, (bf16_t*)out_bf16,
+                       (long)ldob, S, D / 4, total / 4, dropout_p, seed, seed_dev);
+    return hip_status(hipGetLastError());
+  }
   hipLaunchKernelGGL(add_posenc_kernel, dim3(grid_for(total)), dim3(256), 0, S_(stream), a, b, pe, out, (bf16_t*)out_bf16,
                      (long)ldob, S, D, total, dropout_p, seed, seed_dev);
   return hip_status(hipGetLastError());
