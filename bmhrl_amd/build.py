@@ -7,7 +7,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbmhrl_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "attention128.hip", "attention128p.hip", "attention_bwd256.hip", "attention_f16.hip", "attention128_f16.hip", "small_attention.hip",
+SOURCES = ["gemm.hip", "attention.hip", "attention128.hip", "attention128p.hip", "attention_bwd256.hip", "attention_fwd_sk256.hip", "attention_f16.hip", "attention128_f16.hip", "small_attention.hip",
            "memory_attention.hip", "elementwise.hip", "loss.hip", "critic.hip", "conv_gn.hip"]
 HEADERS = ["common.h", "attention_fwd.h", "attention_bwd.h", "attention_pair.h"]
 # attention.hip: the eight 16-register O^T accumulators are loop-carried vector PHIs; AMDGPUCodeGenPrepare would break

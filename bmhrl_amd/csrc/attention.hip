@@ -4,6 +4,11 @@
 #include "attention_fwd.h"
 
 void bmhrl_attn128_set_cfg(int code);   // attention128.hip
+// attention_fwd_sk256.hip: the two-phase exact-softmax form for memories of at most 256 keys
+bool bmhrl_attn256_sk_ok(int B, int H, int Sq, int Sk, long mask_sq, bool force);
+int bmhrl_attn256_sk_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo,
+                         float* row_max, float* row_sum, const uint8_t* mask, int64_t mask_sb, int32_t B, int32_t H, int32_t Sq,
+                         int32_t Sk, float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream);
 
 namespace {
 
@@ -105,8 +110,11 @@ extern "C" int bmhrl_attention_fwd(const void* Q, int64_t ldq, const void* K, in
                                    int64_t mask_sb, int64_t mask_sq, int32_t B, int32_t H, int32_t Sq, int32_t Sk,
                                    int32_t dk, float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                    bmhrl_stream_t stream) {
+  if (dk == 256 && (g_cfg256 == 0 || g_cfg256 == 256) && bmhrl_attn256_sk_ok(B, H, Sq, Sk, mask_sq, g_cfg256 == 256))   // (code 256: this form)
+    return bmhrl_attn256_sk_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, row_max, row_sum, mask, mask_sb, B, H, Sq, Sk, scale, dropout_p, seed,
+                                seed_dev, (hipStream_t)stream);
   return attention256_entry(Q, ldq, K, ldk, V, ldv, O, ldo, row_max, row_sum, mask, mask_sb, mask_sq, B, H, Sq, Sk, dk, scale,
-                            dropout_p, seed, seed_dev, g_cfg256, (hipStream_t)stream);
+                            dropout_p, seed, seed_dev, g_cfg256 == 256 ? 0 : g_cfg256, (hipStream_t)stream);
 }
 
 extern "C" int bmhrl_attn_delta(const void* dO, int64_t lddo, const void* O, int64_t ldo, float* delta, float scale,

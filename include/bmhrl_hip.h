@@ -137,7 +137,8 @@ int bmhrl_attention_shared128_bwd(const void* Qp, int64_t ldq, const void* X, in
 int bmhrl_attention_max_keys(void);
 
 /* Tuning aid: pin the (query blocks x key splits) shape of the attention workgroups -- head_dim 256 or 128; code = 10 * QW + KW
- * (41: 4 x 1, 22: 2 x 2; head_dim 128 also 24: 2 x 4 and 14: the r04 form in which one wave carries two heads over four key
+ * (41: 4 x 1, 22: 2 x 2; head_dim 256 also 256: the two-phase exact-softmax kernel for at most 256 keys, which the automatic
+ * choice takes when the grid fills the chip; head_dim 128 also 24: 2 x 4 and 14: the r04 form in which one wave carries two heads over four key
  * splits, shapes it does not serve fall back to the automatic choice), 0 = automatic (the default).  Process-wide, not
  * thread-safe; results do not depend on it beyond bf16 rounding of P. */
 int bmhrl_attention_config(int32_t head_dim, int32_t code);

@@ -12,10 +12,11 @@ if [ "$1" = "trace" ]; then   # the attention kernels with cycle stamps (-DBMHRL
   $HIPCC $F -c bmhrl_amd/csrc/attention.hip -o tests/kbench/build/attention_t.o &
   $HIPCC $F -mllvm -amdgpu-mfma-vgpr-form -c bmhrl_amd/csrc/attention128.hip -o tests/kbench/build/attention128_t.o &
   $HIPCC $F -c bmhrl_amd/csrc/attention128p.hip -o tests/kbench/build/attention128p_t.o &
+  $HIPCC $F -c bmhrl_amd/csrc/attention_fwd_sk256.hip -o tests/kbench/build/attention_fwd_sk256_t.o &
   $HIPCC $F -DBMHRL_GEMM_TRACE -c bmhrl_amd/csrc/gemm.hip -o tests/kbench/build/gemm_t.o &
   wait
   $HIPCC -O2 -std=c++17 -c tests/kbench/gemm_bench.cpp -o tests/kbench/build/gemm_bench.o
   $HIPCC --offload-arch=gfx950 tests/kbench/build/gemm_bench.o tests/kbench/build/gemm_t.o -o tests/kbench/gemm_bench_trace
   $HIPCC -O2 -std=c++17 -c tests/kbench/attn_bench.cpp -o tests/kbench/build/attn_bench.o
-  $HIPCC --offload-arch=gfx950 tests/kbench/build/attn_bench.o tests/kbench/build/attention_t.o tests/kbench/build/attention128_t.o tests/kbench/build/attention128p_t.o -o tests/kbench/attn_bench_trace
+  $HIPCC --offload-arch=gfx950 tests/kbench/build/attn_bench.o tests/kbench/build/attention_t.o tests/kbench/build/attention128_t.o tests/kbench/build/attention128p_t.o tests/kbench/build/attention_fwd_sk256_t.o -o tests/kbench/attn_bench_trace
 fi

@@ -994,3 +994,59 @@ def test_head_loss_reports_a_non_finite_row_like_the_unfused_tail(dev, poison):
     assert int(counter.abs().sum()) == 0
     clean = fused(logits)
     assert math.isfinite(clean) and abs(clean - unfused(logits)) <= 2e-6 * abs(clean)
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,kind", [(2, 4, 800, 256, "pad"), (2, 4, 200, 250, "pad"), (1, 4, 33, 130, "allmasked"), (2, 4, 64, 20, "pad"),
+                                            (3, 3, 100, 1, "none"), (2, 2, 129, 161, "none"), (16, 4, 800, 256, "pad")])
+def test_attention_fwd_two_phase_form_for_short_memories(dev, B, H, Sq, Sk, kind):
+    """bmhrl_attention_fwd in the exact-softmax two-phase form for at most 256 keys (csrc/attention_fwd_sk256.hip; taken by itself
+    for grids that fill the chip, forced here with config code 256): context, statistics and the output-dropout mask against the
+    float64 reference and against the generic online-softmax kernel on the same inputs."""
+    from bmhrl_amd import _lib, ops
+    dk = 256
+    D = H * dk
+    g = torch.Generator().manual_seed(Sq * 1000 + Sk)
+    Q = bf(torch.randn(B, Sq, D, generator=g)).to(dev)
+    K = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    V = bf(torch.randn(B, Sk, D, generator=g)).to(dev)
+    mask, sb = None, 0
+    if kind == "pad":
+        mask = torch.ones(B, 1, Sk, dtype=torch.uint8)
+        mask[0, 0, Sk - Sk // 3:] = 0
+        mask[-1, 0, 5:9] = 0
+        sb = Sk
+    elif kind == "allmasked":
+        mask = torch.zeros(B, 1, Sk, dtype=torch.uint8)
+        sb = Sk
+    if mask is not None:
+        mask = mask.to(dev).contiguous()
+    scale = 1 / math.sqrt(dk)
+    out = {}
+    try:
+        for code in (256, 41):
+            _lib.check(_lib.load().bmhrl_attention_config(256, code), "bmhrl_attention_config")
+            for p_drop in (0.0, 0.25):
+                O = torch.zeros(B, Sq, D, dtype=torch.bfloat16, device=dev)
+                rmax = torch.empty(B, H, Sq, device=dev)
+                rsum = torch.empty(B, H, Sq, device=dev)
+                ops.attention_fwd(Q, K, V, O, rmax, rsum, mask, sb, 0, B, H, Sq, Sk, dk, scale, D, D, D, D, dropout_p=p_drop, seed=77)
+                torch.cuda.synchronize()
+                out[code, p_drop] = (O.float(), rmax.double().cpu(), rsum.double().cpu())
+    finally:
+        _lib.load().bmhrl_attention_config(256, 0)
+    ref, s = _attn_ref(Q, K, V, mask, H, scale)
+    O, rmax, rsum = out[256, 0.0]
+    assert rel_err(O, ref) < 1.5e-2
+    lse_ref = torch.logsumexp(s, -1).cpu()
+    assert float((rmax + torch.log(rsum) - lse_ref).abs().max()) < 2e-3 * max(1.0, float(lse_ref.abs().max()) * 1e-6 + 1.0)
+    assert float((s.max(-1).values.cpu() - rmax).abs().max()) < 1e-3 * max(1.0, float(rmax.abs().max()) * 1e-6)     # the EXACT maximum
+    if kind == "allmasked":
+        assert float((rmax + 1e9).abs().max()) == 0.0 and float((rsum - Sk).abs().max()) < 1e-3 * Sk
+        assert rel_err(O, V.float().view(B, Sk, D).mean(1, keepdim=True).expand(B, Sq, D)) < 1.5e-2
+    assert rel_err(O, out[41, 0.0][0]) < 1.5e-2                       # the generic kernel on the same inputs
+    # output dropout: the same elements are dropped for the same seed (same element numbering), kept ones scaled by 1 / (1 - p)
+    Od, Og = out[256, 0.25][0], out[41, 0.25][0]
+    big = O.abs() > 1e-2 * O.abs().max()
+    assert torch.equal((Od == 0)[big], (Og == 0)[big])
+    kept = big & (Od != 0)
+    assert rel_err(Od[kept], (O / 0.75)[kept]) < 1.5e-2
