@@ -105,16 +105,38 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_sk256_kernel(const FsArgs p) 
   // keep bits of the (at most 256) keys: thread = key; balloted into LDS behind the last score tile
   const bool keep_t = tid < p.Sk && (p.mask == nullptr || p.mask[(long)b * p.mask_sb + min(tid, p.Sk - 1)] != 0);
 
-  // Q^T fragments: lane (q = r32, h) holds row q, columns 16 st + 8 h .. + 8 -- requested first, then every K tile
+  // Q^T fragments: lane (q = r32, h) holds row q, columns 16 st + 8 h .. + 8.  Read straight from global memory a fragment load
+  // touches 32 rows x 32 bytes; instead the wave's 64 rows go through the (still empty) stage area by direct-to-LDS loads -- whole
+  // 1 KiB pieces, rows swizzled as the K tiles -- and are read back as row fragments.  Wave w uses stages 2 w, 2 w + 1 for its
+  // own rows only, so no barrier is needed before the reads; one is needed before the K tiles overwrite the area.
   bf16x8 qf[QB][16];
+  {
+    const char* __restrict__ Qb = reinterpret_cast<const char*>(p.Q + (long)b * p.Sq * p.ldq + hd * DK);
+    const unsigned ldq2 = (unsigned)p.ldq * 2u;
+    bf16_t* qd = reinterpret_cast<bf16_t*>(smem_raw) + wave * 64 * DK;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int qr = min(q_base + 32 * qb + r32, p.Sq - 1);
-    const bf16_t* qp = p.Q + ((long)b * p.Sq + qr) * p.ldq + hd * DK + 8 * h;
+    for (int i = 0; i < 32; ++i) {
+      const int row = 2 * i + hi;                                      // 0 .. 63 of the wave's rows
+      const unsigned qrow = (unsigned)min(q_base + row, p.Sq - 1);
+      glds16<0>(Qb + (qrow * ldq2 + (unsigned)((pch ^ (row & 15)) << 4)), qd + i * 2 * DK);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned qa = lds0 + wave * 64 * 512 + r32 * 512;
 #pragma unroll
-    for (int st = 0; st < 16; ++st) qf[qb][st] = *reinterpret_cast<const bf16x8*>(qp + 16 * st);
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const unsigned a = qa + qb * 32 * 512 + (((2 * st + h) ^ (r32 & 15)) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qf[qb][st]) : "v"(a));
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int st = 0; st < 16; ++st) asm volatile("" : "+v"(qf[qb][st]));
+    __builtin_amdgcn_s_barrier();                        // every wave has its fragments: the stage area is free for the K tiles
+    asm volatile("" ::: "memory");
   }
-  asm volatile("" ::: "memory");                      // (the Q loads are issued before the K pieces: the counted waits below rely on it)
 #pragma unroll
   for (int t = 0; t < nt; ++t) stage_k(t, t);
   unsigned k_addr[8];
@@ -376,7 +398,7 @@ int bmhrl_attn256_sk_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk,
   BMHRL_CHECK_ARG(ldq >= (int64_t)H * 256 && ldk >= (int64_t)H * 256 && ldv >= (int64_t)H * 256 && ldo >= (int64_t)H * 256);
   BMHRL_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0);
   BMHRL_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
-  BMHRL_CHECK_ARG((int64_t)Sk * ldk * 2 < (1ll << 31) && (int64_t)Sk * ldv * 2 < (1ll << 31));   // 32-bit lane offsets
+  BMHRL_CHECK_ARG((int64_t)Sk * ldk * 2 < (1ll << 31) && (int64_t)Sk * ldv * 2 < (1ll << 31) && (int64_t)Sq * ldq * 2 < (1ll << 31));   // 32-bit lane offsets
   FsArgs a;
   a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
   a.O = (bf16_t*)O; a.ldo = ldo; a.row_max = row_max; a.row_sum = row_sum; a.mask = mask; a.mask_sb = mask_sb;
