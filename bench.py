@@ -174,7 +174,7 @@ def attention_roofline(dev, B, H, Tv, Ta, iters=50):
         "traffic": traffic, "launch_us": sec_va * 1e6, "flops_per_launch": exec_va,
         "shape": {"B": B, "H": H, "Sq": Sq, "Sk": Sk, "d_k": dk, "mask": "padded tails of the synthetic batch"},
         "mfma_issued_frac": tf(issued_va, sec_va) / 2500.0,
-        "cross_modal_A<-V": {"kernel": "attn_fwd_kernel<256> = bmhrl_attention_fwd (Sq = Ta, Sk = Tv, d_k = 256)",
+        "cross_modal_A<-V": {"kernel": "attn_fwd_sk256_kernel = bmhrl_attention_fwd for Sk <= 256 (Sq = Ta, Sk = Tv, d_k = 256; BMHRL_ATTN_SK256=0: attn_fwd_kernel<256>)",
                              "launch_us": sec_av * 1e6, "flops_per_launch": exec_av, "achieved": tf(exec_av, sec_av),
                              "frac": tf(exec_av, sec_av) / 2500.0, "mfma_issued_frac": tf(issued_av, sec_av) / 2500.0},
         "call_equivalent_V<-A": {"what": "4*B*Sq*Sk*1024 flops of the attention call the launch stands for, over the kernel + "
